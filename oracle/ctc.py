@@ -1,0 +1,77 @@
+"""CTC greedy decoding and id -> text, restated in NumPy (test infrastructure).
+
+Follows `utils/text/ctc_decoder.py:14-35` (wrapper around `keras.ops.ctc_decode(strategy='greedy',
+mask_index=0)`) and `utils/text/tokenizer.py:189-219,283-285,599-669` (char-level vocabulary built
+with `setdefault`, blank index 0, ids -> string).
+
+Keras itself is not available here.  The token output is fully determined by argmax + collapse and
+needs no pinning; the score formula (`-sum_t max_v logit[t] / length`, what the TensorFlow greedy
+decoder returns as `neg_sum_logits`, divided by the length in the wrapper) is restated from
+knowledge of Keras 3 and is **parity unpinned**.
+"""
+import numpy as np
+
+
+def ctc_greedy(logits, lengths=None, blank_index=0):
+    """(B,T,V) float32 -> (tokens (B,T) int32 padded with -1, scores (B,) float32).
+
+    argmax over the raw logits (first maximum wins), merge repeats, drop blank, left-pack.
+    """
+    logits = np.asarray(logits, dtype=np.float32)
+    B, T, V = logits.shape
+    if lengths is None:
+        lengths = np.full((B,), T, dtype=np.int32)
+    tokens = np.full((B, T), -1, dtype=np.int32)
+    scores = np.zeros((B,), dtype=np.float32)
+    for b in range(B):
+        L = int(lengths[b])
+        if L == 0:
+            continue
+        idx = np.argmax(logits[b, :L], axis=-1)
+        mx = logits[b, :L][np.arange(L), idx]
+        acc = np.float32(0)
+        for v in mx:                                    # sequential float32 sum over time
+            acc = np.float32(acc + v)
+        scores[b] = np.float32(-acc) / np.float32(L)
+        prev, k = -1, 0
+        for t in range(L):
+            tok = int(idx[t])
+            if tok != prev and tok != blank_index:
+                tokens[b, k] = tok
+                k += 1
+            prev = tok
+    return tokens, scores
+
+
+class CharTokenizer:
+    """Char-level vocabulary as the reference tokenizer builds it (tokenizer.py:189-219).
+
+    Ids are assigned with `dict.setdefault`, so a character that appears twice in the vocabulary
+    keeps its first id and every later character moves up by one; `vocab_size` shrinks accordingly.
+    """
+
+    def __init__(self, characters, blank='<blank>'):
+        self.symbol_to_id = {}
+        for s in [blank] + list(characters):
+            self.symbol_to_id.setdefault(s, len(self.symbol_to_id))
+        self.id_to_symbol = {i: s for s, i in self.symbol_to_id.items()}
+        self.blank_token_idx = self.symbol_to_id[blank]
+
+    @property
+    def vocab_size(self):
+        return len(self.id_to_symbol)
+
+    def decode(self, tokens):
+        """tokenizer.py:599-656 for one row of ids (skip_padding=True)."""
+        tokens = [int(t) for t in tokens]
+        symbols = []
+        for i, tok in enumerate(tokens):
+            if tok != self.blank_token_idx:
+                symbols.append(tok)
+            if tok == self.blank_token_idx and i < len(tokens) - 1 and tokens[i + 1] == self.blank_token_idx:
+                break
+        return ''.join(self.id_to_symbol.get(t, '') for t in symbols)
+
+    def ctc_decode(self, logits, lengths=None):
+        tokens, scores = ctc_greedy(logits, lengths, self.blank_token_idx)
+        return [self.decode(t) for t in tokens], scores
