@@ -1,0 +1,184 @@
+/*
+ * ocrhip.h - C ABI of libocrhip.so: the OCR inference hot path on MI355X (gfx950).
+ *
+ *   image -> EAST-VGG16 -> RBOX decode -> locality-aware NMS -> crop / resize -> CRNN -> CTC greedy
+ *
+ * Every entry point replaces a piece of Python / Keras / NumPy in the reference repository; the
+ * reference interface each one stands in for is cited as path:line (paths relative to the
+ * reference checkout).  Conventions:
+ *
+ *   - return 0 (OCRHIP_OK) or a negative OCRHIP_E* code; ocrhip_last_error() gives the text
+ *     (thread-local);
+ *   - every pointer named "d_*" or documented as "device" is device memory of the handle's GPU;
+ *     everything else is host memory;
+ *   - calls are asynchronous on the given stream (a hipStream_t passed as void*, NULL = the
+ *     default stream); nothing synchronises the device unless stated;
+ *   - the library never frees or keeps caller buffers; outputs are caller-allocated;
+ *   - one handle per (device, host thread); a handle owns the network weights and a grow-only
+ *     activation workspace (hipMalloc happens in *_load_weights and when a forward call needs a
+ *     larger workspace than any call before it).
+ */
+#ifndef OCRHIP_H
+#define OCRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ocrhip_ctx* ocrhip_handle;
+typedef void* ocrhip_stream; /* hipStream_t */
+
+enum {
+    OCRHIP_OK = 0,
+    OCRHIP_EINVAL = -1, /* bad argument / shape the kernels do not support               */
+    OCRHIP_ECAP = -2,   /* a caller-provided capacity is too small                        */
+    OCRHIP_EHIP = -3,   /* a HIP runtime call failed                                      */
+    OCRHIP_ESTATE = -4  /* weights not loaded / handle not usable                         */
+};
+
+enum { OCRHIP_F32 = 0, OCRHIP_BF16 = 1, OCRHIP_U8 = 2 };
+enum { OCRHIP_MERGE_UNION = 0, OCRHIP_MERGE_AVERAGE = 1 };
+
+/* A named host tensor handed to *_load_weights.  Names and layouts are those of the original
+ * torch checkpoints the reference converts from (models/weights_converter.py:252-322):
+ * conv OIHW, linear (out,in), LSTM (4H,in) with gate rows i,f,g,o, batch-norm
+ * weight/bias/running_mean/running_var. */
+typedef struct {
+    const char* name;
+    const float* data; /* host, float32, C-contiguous */
+    int ndim;
+    int64_t shape[4];
+} ocrhip_tensor_desc;
+
+int ocrhip_version(void);
+const char* ocrhip_last_error(void);
+
+/* Handle lifetime.  Replaces model construction through the runtime switch
+ * (models/interfaces/base_model.py:179-189, utils/keras/runtimes/__init__.py:23-36). */
+int ocrhip_create(int device, ocrhip_handle* out);
+int ocrhip_destroy(ocrhip_handle h);
+
+/* ------------------------------------------------------------------------------------ EAST --
+ * Weights of EASTVGG (architectures/east_arch.py:95-175), keys of SakuraRiven's east_vgg16.pth:
+ *   extractor.features.{0,3,7,10,14,17,20,24,27,30,34,37,40}.{weight,bias}   conv 3x3
+ *   extractor.features.{idx+1}.{weight,bias,running_mean,running_var}        batch-norm
+ *   merge.conv{1..7}.{weight,bias}, merge.bn{1..7}.{weight,bias,running_mean,running_var}
+ *   output.conv{1,2,3}.{weight,bias}
+ * Batch-norm (eps 1e-5) is folded into the preceding convolution at load time. */
+int ocrhip_east_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n);
+
+/* EAST forward: replaces `compiled_infer(inputs)` in BaseDetector.infer
+ * (models/detection/base_detector.py:72-76) and, for in_dtype == OCRHIP_U8, also the
+ * `/255` + 'east' normalisation `(x - 0.5) / 0.5` (utils/image/image_normalization.py:57,
+ * models/interfaces/base_image_model.py:127-131).
+ *   d_img : device, (B,H,W,3) NHWC, uint8 raw pixels or float32 already normalised; H, W % 32 == 0
+ *   d_maps: device, (B,H/4,W/4,6) float32 = [score, d_top, d_bottom, d_left, d_right, angle],
+ *           sigmoid outputs exactly as the Keras model returns them
+ *   compute_dtype: OCRHIP_F32 (f32 MFMA, exact float32 products) or OCRHIP_BF16 */
+int ocrhip_east_forward(ocrhip_handle h, const void* d_img, int B, int H, int W, int in_dtype,
+                        int compute_dtype, float* d_maps, ocrhip_stream stream);
+
+/* Debug / test access to an activation of the last ocrhip_east_forward call (synchronises).
+ *   name: "pool1".."pool5", "merge2", "merge4", "merge7"
+ *   shape receives (B,H,W,C); *n_elems the element count; dst (host, float32) may be NULL to query. */
+int ocrhip_east_get_activation(ocrhip_handle h, const char* name, float* dst, int64_t dst_capacity,
+                               int64_t shape[4]);
+
+/* Score threshold + RBOX decode + validity filter + /(W,H) + poly -> xyxy.  Replaces
+ * restore_polys_from_map / restore_polys / filter_polys (models/detection/east.py:102-187), the map
+ * scaling in EAST.decode_output (east.py:81-85) and the poly branch of convert_box_format
+ * (utils/image/bounding_box/converter.py:151-154,165-166).
+ *   d_maps  : device (B,mh,mw,6) float32 from ocrhip_east_forward
+ *   in_h/w  : network input size (the reference's `inputs.shape[1:-1]`), scale = in / map
+ *   cap     : slots per image in the outputs; image b owns [b*cap, b*cap + counts[b])
+ *   d_xyxy  : device (B*cap,4) float32 relative xyxy            (required)
+ *   d_polys : device (B*cap,8) float32 relative corners, or NULL
+ *   d_scores: device (B*cap)   float32                           (required)
+ *   d_pix   : device (B*cap)   int32 map pixel index y*mw+x, or NULL
+ *   d_counts: device (B)       int32 number of boxes found; if counts[b] > cap only the first cap
+ *             (row-major order) were stored - the caller checks this after synchronising.
+ * Output order inside an image is row-major over the map. */
+int ocrhip_east_decode(ocrhip_handle h, const float* d_maps, int B, int mh, int mw, int in_h, int in_w,
+                       float obj_threshold, int cap, float* d_xyxy, float* d_polys, float* d_scores,
+                       int* d_pix, int* d_counts, ocrhip_stream stream);
+
+/* Locality-aware NMS followed (when nms_threshold < merge_threshold) by matrix NMS.  Replaces
+ * lanms / self_merging / _merge_boxes (utils/image/bounding_box/locality_aware_nms.py:22-126),
+ * fast_nms / self_suppression (non_max_suppression.py:117-138,191-220) and _sort_boxes (:247-253).
+ * Rank = score descending, ties towards the lower input index.
+ *   d_xyxy, d_scores, d_counts, cap: as written by ocrhip_east_decode (any xyxy boxes work)
+ *   max_iter  : <= 0 means "number of boxes" (the reference default)
+ *   max_out   : <= 0 means unlimited (the reference's max_output_size=None)
+ *   d_merged  : device (B*cap,4) merged boxes in INPUT order (suppressed boxes are 0), or NULL
+ *   d_keep    : device (B*cap) uint8 valid mask in INPUT order, or NULL
+ *   d_out_boxes / d_out_scores / d_out_src: device (B*cap,4)/(B*cap)/(B*cap): the kept boxes of image b
+ *               in RANK order at [b*cap, b*cap + out_counts[b]); src = input index inside the image
+ *   d_out_counts: device (B) int32;  d_n_iter: device (B) int32 merge iterations run, or NULL */
+int ocrhip_lanms(ocrhip_handle h, const float* d_xyxy, const float* d_scores, const int* d_counts, int B,
+                 int cap, float merge_threshold, float nms_threshold, int merge_method, int max_iter,
+                 int max_out, float* d_merged, uint8_t* d_keep, float* d_out_boxes, float* d_out_scores,
+                 int* d_out_src, int* d_out_counts, int* d_n_iter, ocrhip_stream stream);
+
+/* ------------------------------------------------------------------------------ crop / pack --
+ * Crop + /255 + grayscale + antialiased bilinear resize + repeat-last padding + 'easyocr'
+ * normalisation, packed for the recogniser.  Replaces crop_box
+ * (utils/image/bounding_box/processing.py:111-132), the tail of load_image
+ * (utils/image/image_io.py:122-135), resize_image / pad_image
+ * (utils/image/image_processing.py:17-142) and the normalisation
+ * (utils/image/image_normalization.py:58) for the CRNN arguments of models/ocr/crnn.py:39-45.
+ *   d_img    : device (B,H,W,3) uint8
+ *   d_rects  : device (n,4) int32 absolute x0,y0,x1,y1 already resolved to the slice the reference
+ *              takes (0 <= x0 < x1 <= W ...); sizes are computed on the host with the reference's
+ *              float32 arithmetic
+ *   d_box_img: device (n) int32 image index of each crop
+ *   d_inter  : device (n,2) int32 (h,w) the crop is resized to before padding
+ *   d_out_w  : device (n) int32 padded width of each crop (multiple of 64)
+ *   d_dst_off: device (n) int64 element offset of each crop's (out_h,out_w) plane in d_packed
+ *   d_packed : device, float32 (or bf16) planes, row-major (out_h, out_w), value (x-0.5)/0.5 */
+int ocrhip_crop_resize_pack(ocrhip_handle h, const uint8_t* d_img, int B, int H, int W, const int* d_rects,
+                            const int* d_box_img, const int* d_inter, const int* d_out_w,
+                            const int64_t* d_dst_off, int n, int out_h, void* d_packed, int out_dtype,
+                            ocrhip_stream stream);
+
+/* ------------------------------------------------------------------------------------ CRNN --
+ * Weights of CRNNCTC with the VGG extractor (architectures/crnn_arch.py:38-41,306-328,427-531),
+ * keys of EasyOCR's recogniser checkpoints without the "module." prefix:
+ *   FeatureExtraction.ConvNet.{0,3,6,8,18}.{weight,bias}, FeatureExtraction.ConvNet.{11,14}.weight,
+ *   FeatureExtraction.ConvNet.{12,15}.{weight,bias,running_mean,running_var},
+ *   SequenceModeling.{0,1}.rnn.{weight_ih_l0,weight_hh_l0,bias_ih_l0,bias_hh_l0}[_reverse],
+ *   SequenceModeling.{0,1}.linear.{weight,bias}, Prediction.{weight,bias}
+ * The vocabulary size is the row count of Prediction.weight. */
+int ocrhip_crnn_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n);
+
+/* CRNN forward + optional fused CTC greedy.  Replaces `compiled_infer(inp[None])` per text row in
+ * BaseOCR.infer (models/ocr/base_ocr.py:171-201) for a whole batch of equal-width crops, and (when
+ * d_tokens != NULL) pad_batch + ctc_decode (base_ocr.py:209-222, utils/text/ctc_decoder.py:14-35).
+ *   d_crops : device (n,64,Wpad,1) float32 normalised crops (ocrhip_crop_resize_pack output)
+ *   d_logits: device (n,T,V) float32 raw logits, T = Wpad/4 - 1, or NULL
+ *   d_tokens: device (n,T) int32 greedy tokens padded with -1, or NULL
+ *   d_scores: device (n) float32 -sum_t max_v logit / T, or NULL (required with d_tokens) */
+int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, int compute_dtype,
+                        float* d_logits, int* d_tokens, float* d_scores, ocrhip_stream stream);
+int ocrhip_crnn_vocab_size(ocrhip_handle h);
+
+/* Debug / test access to an activation of the last ocrhip_crnn_forward call (synchronises).
+ *   name: "features" (n,T,256), "seq0", "seq1" (n,T,256) */
+int ocrhip_crnn_get_activation(ocrhip_handle h, const char* name, float* dst, int64_t dst_capacity,
+                               int64_t shape[4]);
+
+/* CTC greedy decoding of padded logits.  Replaces ctc_decode(method='greedy')
+ * (utils/text/ctc_decoder.py:14-35 -> keras.ops.ctc_decode): argmax over the raw logits (first
+ * maximum wins), merge repeats, drop `blank`, left-pack, pad with -1;
+ * score = -sum_{t<len} max_v logit[t] / len.
+ *   d_logits : device (B,T,V) float32;  d_lengths: device (B) int32 or NULL (= T)
+ *   d_tokens : device (B,T) int32;      d_scores : device (B) float32 */
+int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int V, const int* d_lengths,
+                      int blank, int* d_tokens, float* d_scores, ocrhip_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCRHIP_H */

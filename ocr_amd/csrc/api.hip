@@ -1,0 +1,494 @@
+// C ABI of libocrhip.so: handle lifetime, weight loading (batch-norm folding, device layouts) and
+// the two network graphs.  The graphs follow architectures/east_arch.py:95-175 and
+// architectures/crnn_arch.py:38-41,306-328,427-531 layer by layer; each layer is one launch of a
+// kernel from conv_direct.hip / conv_mfma.hip / rnn.hip.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace ocrhip {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+int DevBuf::reserve(size_t need) {
+    if (need <= bytes && ptr) return OCRHIP_OK;
+    if (ptr) {
+        OCR_HIP_CHECK(hipFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+    }
+    if (need == 0) need = 256;
+    OCR_HIP_CHECK(hipMalloc(&ptr, need));
+    bytes = need;
+    return OCRHIP_OK;
+}
+
+void DevBuf::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+namespace {
+
+constexpr double kBnEps = 1e-5;
+
+struct Weights {
+    const ocrhip_tensor_desc* w;
+    int n;
+    const ocrhip_tensor_desc* find(const std::string& name) const {
+        for (int i = 0; i < n; ++i)
+            if (w[i].name && name == w[i].name) return &w[i];
+        return nullptr;
+    }
+};
+
+int64_t numel(const ocrhip_tensor_desc& t) {
+    int64_t k = 1;
+    for (int i = 0; i < t.ndim; ++i) k *= t.shape[i];
+    return k;
+}
+
+int get(const Weights& W, const std::string& name, std::initializer_list<int64_t> shape, const float** out) {
+    const ocrhip_tensor_desc* t = W.find(name);
+    if (!t || !t->data) {
+        set_error("load_weights: tensor '%s' is missing", name.c_str());
+        return OCRHIP_EINVAL;
+    }
+    int64_t want = 1;
+    for (int64_t s : shape) want *= s;
+    if (numel(*t) != want) {
+        set_error("load_weights: tensor '%s' has %lld elements, expected %lld", name.c_str(), (long long)numel(*t),
+                  (long long)want);
+        return OCRHIP_EINVAL;
+    }
+    *out = t->data;
+    return OCRHIP_OK;
+}
+
+// conv (+ optional bias) followed by inference batch-norm -> folded weight / bias
+int fold_conv_bn(const Weights& W, const std::string& conv, const std::string& bn, bool has_bias, int cout, int cin,
+                 int ks, std::vector<float>& w_out, std::vector<float>& b_out) {
+    const float *w = nullptr, *b = nullptr;
+    OCR_TRY(get(W, conv + ".weight", {cout, cin, ks, ks}, &w));
+    if (has_bias) OCR_TRY(get(W, conv + ".bias", {cout}, &b));
+    const size_t per_out = (size_t)cin * ks * ks;
+    w_out.assign(w, w + (size_t)cout * per_out);
+    b_out.assign((size_t)cout, 0.0f);
+    if (b) b_out.assign(b, b + cout);
+    if (!bn.empty()) {
+        const float *g = nullptr, *beta = nullptr, *mean = nullptr, *var = nullptr;
+        OCR_TRY(get(W, bn + ".weight", {cout}, &g));
+        OCR_TRY(get(W, bn + ".bias", {cout}, &beta));
+        OCR_TRY(get(W, bn + ".running_mean", {cout}, &mean));
+        OCR_TRY(get(W, bn + ".running_var", {cout}, &var));
+        for (int o = 0; o < cout; ++o) {
+            const double sc = (double)g[o] / std::sqrt((double)var[o] + kBnEps);
+            for (size_t i = 0; i < per_out; ++i) w_out[(size_t)o * per_out + i] = (float)((double)w_out[(size_t)o * per_out + i] * sc);
+            b_out[o] = (float)(((double)b_out[o] - (double)mean[o]) * sc + (double)beta[o]);
+        }
+    }
+    return OCRHIP_OK;
+}
+
+const int kEastVggIdx[13] = {0, 3, 7, 10, 14, 17, 20, 24, 27, 30, 34, 37, 40};
+const int kEastVggCout[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+const int kEastVggPool[13] = {0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1};
+const int kMergeCin[7] = {1024, 128, 384, 64, 192, 32, 32};
+const int kMergeCout[7] = {128, 128, 64, 64, 32, 32, 32};
+const int kMergeKs[7] = {1, 3, 1, 3, 1, 3, 3};
+
+void record(std::map<std::string, Activation>& taps, const char* name, const float* p, int64_t b, int64_t h, int64_t w,
+            int64_t c) {
+    Activation a;
+    a.ptr = p;
+    a.shape[0] = b; a.shape[1] = h; a.shape[2] = w; a.shape[3] = c;
+    taps[name] = a;
+}
+
+int read_activation(const std::map<std::string, Activation>& taps, const char* name, float* dst, int64_t cap,
+                    int64_t shape[4]) {
+    OCR_REQUIRE(name && shape, "get_activation: null argument");
+    auto it = taps.find(name);
+    OCR_REQUIRE(it != taps.end(), "get_activation: no activation named '%s' (run a forward first)", name);
+    int64_t k = 1;
+    for (int i = 0; i < 4; ++i) {
+        shape[i] = it->second.shape[i];
+        k *= shape[i];
+    }
+    if (!dst) return OCRHIP_OK;
+    if (cap < k) {
+        set_error("get_activation: destination holds %lld elements, %lld needed", (long long)cap, (long long)k);
+        return OCRHIP_ECAP;
+    }
+    OCR_HIP_CHECK(hipDeviceSynchronize());
+    OCR_HIP_CHECK(hipMemcpy(dst, it->second.ptr, (size_t)k * sizeof(float), hipMemcpyDeviceToHost));
+    return OCRHIP_OK;
+}
+
+}  // namespace
+}  // namespace ocrhip
+
+using namespace ocrhip;
+
+#define OCR_HANDLE(h)                                               \
+    do {                                                            \
+        if (!(h)) {                                                 \
+            ocrhip::set_error("null handle");                       \
+            return OCRHIP_EINVAL;                                   \
+        }                                                           \
+        OCR_HIP_CHECK(hipSetDevice((h)->device));                   \
+    } while (0)
+
+extern "C" {
+
+int ocrhip_version(void) { return 100; }
+
+const char* ocrhip_last_error(void) { return ocrhip::g_error; }
+
+int ocrhip_create(int device, ocrhip_handle* out) {
+    OCR_REQUIRE(out, "create: null output pointer");
+    int count = 0;
+    OCR_HIP_CHECK(hipGetDeviceCount(&count));
+    OCR_REQUIRE(device >= 0 && device < count, "create: device %d not available (%d devices)", device, count);
+    OCR_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    OCR_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("create: device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
+        return OCRHIP_ESTATE;
+    }
+    ocrhip_ctx* h = new ocrhip_ctx();
+    h->device = device;
+    *out = h;
+    return OCRHIP_OK;
+}
+
+int ocrhip_destroy(ocrhip_handle h) {
+    if (!h) return OCRHIP_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.bias.release(); };
+    for (auto& L : h->east.vgg) free_layer(L);
+    for (auto& L : h->east.merge) free_layer(L);
+    free_layer(h->east.head);
+    for (auto& b : h->east.act) b.release();
+    for (auto& b : h->east.pool) b.release();
+    for (auto& L : h->crnn.conv) free_layer(L);
+    for (int l = 0; l < 2; ++l) {
+        for (int d = 0; d < 2; ++d) {
+            free_layer(h->crnn.wih[l][d]);
+            h->crnn.whh[l][d].release();
+        }
+        free_layer(h->crnn.linear[l]);
+    }
+    free_layer(h->crnn.pred);
+    for (auto& b : h->crnn.act) b.release();
+    for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits})
+        b->release();
+    h->decode_stage.release();
+    h->lanms_ws.release();
+    delete h;
+    return OCRHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ EAST
+
+int ocrhip_east_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n) {
+    OCR_HANDLE(h);
+    OCR_REQUIRE(w && n > 0, "east_load_weights: no tensors");
+    Weights W{w, n};
+    EastNet& net = h->east;
+    net.loaded = false;
+    std::vector<float> wf, bf;
+    int cin = 3;
+    for (int i = 0; i < 13; ++i) {
+        const std::string conv = "extractor.features." + std::to_string(kEastVggIdx[i]);
+        const std::string bn = "extractor.features." + std::to_string(kEastVggIdx[i] + 1);
+        OCR_TRY(fold_conv_bn(W, conv, bn, true, kEastVggCout[i], cin, 3, wf, bf));
+        if (i == 0)
+            OCR_TRY(prepare_conv_direct(net.vgg[i], wf.data(), bf.data(), kEastVggCout[i], cin, 3));
+        else
+            OCR_TRY(prepare_conv_mfma(net.vgg[i], wf.data(), bf.data(), kEastVggCout[i], cin, 3));
+        cin = kEastVggCout[i];
+    }
+    for (int k = 0; k < 7; ++k) {
+        const std::string conv = "merge.conv" + std::to_string(k + 1), bn = "merge.bn" + std::to_string(k + 1);
+        OCR_TRY(fold_conv_bn(W, conv, bn, true, kMergeCout[k], kMergeCin[k], kMergeKs[k], wf, bf));
+        OCR_TRY(prepare_conv_mfma(net.merge[k], wf.data(), bf.data(), kMergeCout[k], kMergeCin[k], kMergeKs[k]));
+    }
+    {
+        // heads: output.conv1 (score), output.conv2 (4 distances), output.conv3 (angle) -> [6][32]
+        std::vector<float> hw(6 * 32), hb(6);
+        const int rows[3] = {1, 4, 1};
+        int r0 = 0;
+        for (int k = 0; k < 3; ++k) {
+            const float *pw = nullptr, *pb = nullptr;
+            const std::string name = "output.conv" + std::to_string(k + 1);
+            OCR_TRY(get(W, name + ".weight", {rows[k], 32, 1, 1}, &pw));
+            OCR_TRY(get(W, name + ".bias", {rows[k]}, &pb));
+            std::memcpy(hw.data() + r0 * 32, pw, sizeof(float) * rows[k] * 32);
+            std::memcpy(hb.data() + r0, pb, sizeof(float) * rows[k]);
+            r0 += rows[k];
+        }
+        ConvLayer& L = net.head;
+        L.cin = 32; L.cout = 6; L.ks = 1; L.cout_pad = 6; L.direct = true;
+        OCR_TRY(L.w_f32.reserve(hw.size() * sizeof(float)));
+        OCR_TRY(L.bias.reserve(hb.size() * sizeof(float)));
+        OCR_HIP_CHECK(hipMemcpy(L.w_f32.ptr, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice));
+        OCR_HIP_CHECK(hipMemcpy(L.bias.ptr, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    net.loaded = true;
+    return OCRHIP_OK;
+}
+
+int ocrhip_east_forward(ocrhip_handle h, const void* d_img, int B, int H, int W, int in_dtype, int compute_dtype,
+                        float* d_maps, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    EastNet& net = h->east;
+    if (!net.loaded) {
+        set_error("east_forward: weights not loaded");
+        return OCRHIP_ESTATE;
+    }
+    OCR_REQUIRE(d_img && d_maps, "east_forward: null buffer");
+    OCR_REQUIRE(B > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, "east_forward: H and W must be positive multiples of 32 (B=%d H=%d W=%d)", B, H, W);
+    OCR_REQUIRE(in_dtype == OCRHIP_U8 || in_dtype == OCRHIP_F32, "east_forward: in_dtype must be U8 or F32");
+    OCR_REQUIRE(compute_dtype == OCRHIP_F32, "east_forward: compute dtype %d not available in this build", compute_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t px = (size_t)B * H * W;
+    OCR_TRY(net.act[0].reserve(px * 64 * sizeof(float)));
+    OCR_TRY(net.act[1].reserve(px * 32 * sizeof(float)));
+    const int pool_c[5] = {64, 128, 256, 512, 512};
+    for (int i = 0; i < 5; ++i) OCR_TRY(net.pool[i].reserve((px >> (2 * (i + 1))) * pool_c[i] * sizeof(float)));
+    float* A = net.act[0].as<float>();
+    float* Bf = net.act[1].as<float>();
+    net.taps.clear();
+
+    // VGG16-BN body; a convolution followed by 'M' writes the pooled tensor directly
+    OCR_TRY(launch_conv_first(net.vgg[0], d_img, in_dtype == OCRHIP_U8, A, B, H, W, 0, s));
+    const float* cur = A;
+    int ch = H, cw = W, np = 0;
+    for (int i = 1; i < 13; ++i) {
+        float* dst;
+        if (kEastVggPool[i])
+            dst = net.pool[np].as<float>();
+        else
+            dst = (cur == A) ? Bf : A;
+        OCR_TRY(launch_conv_mfma(net.vgg[i], cur, dst, B, ch, cw, kEastVggPool[i] ? 1 : 0, true, nullptr, 0, s));
+        if (kEastVggPool[i]) {
+            ch /= 2; cw /= 2;
+            const std::string name = "pool" + std::to_string(np + 1);
+            record(net.taps, name.c_str(), dst, B, ch, cw, pool_c[np]);
+            ++np;
+        }
+        cur = dst;
+    }
+    // merge branch: [upsample x2 + concat + 1x1] then 3x3 (two of them at the last stage)
+    const float* up = net.pool[4].as<float>();
+    int up_c = 512;
+    int mh = H / 32, mw = W / 32;
+    int k = 0;
+    for (int stage = 0; stage < 3; ++stage) {
+        mh *= 2; mw *= 2;
+        const float* res = net.pool[3 - stage].as<float>();
+        OCR_TRY(launch_conv_mfma(net.merge[k], res, A, B, mh, mw, 0, true, up, up_c, s));
+        ++k;
+        OCR_TRY(launch_conv_mfma(net.merge[k], A, Bf, B, mh, mw, 0, true, nullptr, 0, s));
+        ++k;
+        const float* last = Bf;
+        if (stage == 2) {
+            OCR_TRY(launch_conv_mfma(net.merge[k], Bf, A, B, mh, mw, 0, true, nullptr, 0, s));
+            ++k;
+            last = A;
+        }
+        const std::string name = "merge" + std::to_string(k);
+        record(net.taps, name.c_str(), last, B, mh, mw, kMergeCout[k - 1]);
+        up = last;
+        up_c = kMergeCout[k - 1];
+    }
+    OCR_TRY(launch_east_heads(net.head, up, d_maps, (int64_t)B * mh * mw, s));
+    return OCRHIP_OK;
+}
+
+int ocrhip_east_get_activation(ocrhip_handle h, const char* name, float* dst, int64_t dst_capacity, int64_t shape[4]) {
+    OCR_HANDLE(h);
+    return read_activation(h->east.taps, name, dst, dst_capacity, shape);
+}
+
+int ocrhip_east_decode(ocrhip_handle h, const float* d_maps, int B, int mh, int mw, int in_h, int in_w,
+                       float obj_threshold, int cap, float* d_xyxy, float* d_polys, float* d_scores, int* d_pix,
+                       int* d_counts, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    return launch_east_decode(h, d_maps, B, mh, mw, in_h, in_w, obj_threshold, cap, d_xyxy, d_polys, d_scores, d_pix,
+                              d_counts, (hipStream_t)stream);
+}
+
+int ocrhip_lanms(ocrhip_handle h, const float* d_xyxy, const float* d_scores, const int* d_counts, int B, int cap,
+                 float merge_threshold, float nms_threshold, int merge_method, int max_iter, int max_out, float* d_merged,
+                 uint8_t* d_keep, float* d_out_boxes, float* d_out_scores, int* d_out_src, int* d_out_counts,
+                 int* d_n_iter, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    return launch_lanms(h, d_xyxy, d_scores, d_counts, B, cap, merge_threshold, nms_threshold, merge_method, max_iter,
+                        max_out, d_merged, d_keep, d_out_boxes, d_out_scores, d_out_src, d_out_counts, d_n_iter,
+                        (hipStream_t)stream);
+}
+
+int ocrhip_crop_resize_pack(ocrhip_handle h, const uint8_t* d_img, int B, int H, int W, const int* d_rects,
+                            const int* d_box_img, const int* d_inter, const int* d_out_w, const int64_t* d_dst_off,
+                            int n, int out_h, void* d_packed, int out_dtype, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    return launch_crop_resize_pack(d_img, B, H, W, d_rects, d_box_img, d_inter, d_out_w, d_dst_off, n, out_h, d_packed,
+                                   out_dtype, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------ CRNN
+
+int ocrhip_crnn_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n) {
+    OCR_HANDLE(h);
+    OCR_REQUIRE(w && n > 0, "crnn_load_weights: no tensors");
+    Weights W{w, n};
+    CrnnNet& net = h->crnn;
+    net.loaded = false;
+    // (Sequential index, cin, cout, kernel, bias, batch-norm index or -1), crnn_arch.py:38-41
+    const int cfg[7][6] = {{0, 1, 32, 3, 1, -1},    {3, 32, 64, 3, 1, -1},   {6, 64, 128, 3, 1, -1}, {8, 128, 128, 3, 1, -1},
+                           {11, 128, 256, 3, 0, 12}, {14, 256, 256, 3, 0, 15}, {18, 256, 256, 2, 1, -1}};
+    std::vector<float> wf, bf;
+    for (int i = 0; i < 7; ++i) {
+        const std::string conv = "FeatureExtraction.ConvNet." + std::to_string(cfg[i][0]);
+        const std::string bn = cfg[i][5] >= 0 ? "FeatureExtraction.ConvNet." + std::to_string(cfg[i][5]) : std::string();
+        OCR_TRY(fold_conv_bn(W, conv, bn, cfg[i][4] != 0, cfg[i][2], cfg[i][1], cfg[i][3], wf, bf));
+        if (i == 0)
+            OCR_TRY(prepare_conv_direct(net.conv[i], wf.data(), bf.data(), cfg[i][2], cfg[i][1], cfg[i][3]));
+        else
+            OCR_TRY(prepare_conv_mfma(net.conv[i], wf.data(), bf.data(), cfg[i][2], cfg[i][1], cfg[i][3]));
+    }
+    const int Hd = net.hidden;
+    for (int l = 0; l < 2; ++l) {
+        const std::string pre = "SequenceModeling." + std::to_string(l);
+        for (int d = 0; d < 2; ++d) {
+            const std::string suf = d ? "_reverse" : "";
+            const float *wih = nullptr, *whh = nullptr, *bih = nullptr, *bhh = nullptr;
+            OCR_TRY(get(W, pre + ".rnn.weight_ih_l0" + suf, {4 * Hd, Hd}, &wih));
+            OCR_TRY(get(W, pre + ".rnn.weight_hh_l0" + suf, {4 * Hd, Hd}, &whh));
+            OCR_TRY(get(W, pre + ".rnn.bias_ih_l0" + suf, {4 * Hd}, &bih));
+            OCR_TRY(get(W, pre + ".rnn.bias_hh_l0" + suf, {4 * Hd}, &bhh));
+            std::vector<float> bsum(4 * Hd);
+            for (int i = 0; i < 4 * Hd; ++i) bsum[i] = bih[i] + bhh[i];
+            OCR_TRY(prepare_conv_mfma(net.wih[l][d], wih, bsum.data(), 4 * Hd, Hd, 1));
+            OCR_TRY(net.whh[l][d].reserve((size_t)4 * Hd * Hd * sizeof(float)));
+            OCR_HIP_CHECK(hipMemcpy(net.whh[l][d].ptr, whh, (size_t)4 * Hd * Hd * sizeof(float), hipMemcpyHostToDevice));
+        }
+        const float *lw = nullptr, *lb = nullptr;
+        OCR_TRY(get(W, pre + ".linear.weight", {Hd, 2 * Hd}, &lw));
+        OCR_TRY(get(W, pre + ".linear.bias", {Hd}, &lb));
+        OCR_TRY(prepare_conv_mfma(net.linear[l], lw, lb, Hd, 2 * Hd, 1));
+    }
+    {
+        const ocrhip_tensor_desc* t = W.find("Prediction.weight");
+        OCR_REQUIRE(t && t->data && t->ndim == 2 && t->shape[1] == Hd && t->shape[0] > 0,
+                    "crnn_load_weights: Prediction.weight must be (vocab, %d)", Hd);
+        const int V = (int)t->shape[0];
+        const float* pb = nullptr;
+        OCR_TRY(get(W, "Prediction.bias", {V}, &pb));
+        OCR_TRY(prepare_conv_mfma(net.pred, t->data, pb, V, Hd, 1));
+        net.vocab = V;
+        net.vocab_pad = net.pred.cout_pad;
+    }
+    net.loaded = true;
+    return OCRHIP_OK;
+}
+
+int ocrhip_crnn_vocab_size(ocrhip_handle h) { return (h && h->crnn.loaded) ? h->crnn.vocab : 0; }
+
+int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, int compute_dtype, float* d_logits,
+                        int* d_tokens, float* d_scores, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    CrnnNet& net = h->crnn;
+    if (!net.loaded) {
+        set_error("crnn_forward: weights not loaded");
+        return OCRHIP_ESTATE;
+    }
+    OCR_REQUIRE(d_crops && n > 0 && Wpad >= 8 && Wpad % 4 == 0, "crnn_forward: bad arguments n=%d Wpad=%d", n, Wpad);
+    OCR_REQUIRE(compute_dtype == OCRHIP_F32, "crnn_forward: compute dtype %d not available in this build", compute_dtype);
+    OCR_REQUIRE(d_logits || d_tokens, "crnn_forward: ask for logits and/or tokens");
+    OCR_REQUIRE(!d_tokens || d_scores, "crnn_forward: d_scores is required with d_tokens");
+    hipStream_t s = (hipStream_t)stream;
+    const int Hin = 64, Hd = net.hidden;
+    const int T = Wpad / 4 - 1;
+    OCR_REQUIRE(T >= 1, "crnn_forward: crop too narrow");
+    const size_t nW = (size_t)n * Wpad;
+    OCR_TRY(net.act[0].reserve(nW * 512 * sizeof(float)));      // (n,32,W/2,32) is the largest
+    OCR_TRY(net.act[1].reserve(nW * 256 * sizeof(float)));      // (n,16,W/4,64)
+    float* A = net.act[0].as<float>();
+    float* Bf = net.act[1].as<float>();
+    const float* x = reinterpret_cast<const float*>(d_crops);
+
+    OCR_TRY(launch_conv_first(net.conv[0], x, false, A, n, Hin, Wpad, 1, s));                       // (n,32,W/2,32)
+    OCR_TRY(launch_conv_mfma(net.conv[1], A, Bf, n, 32, Wpad / 2, 1, true, nullptr, 0, s));         // (n,16,W/4,64)
+    OCR_TRY(launch_conv_mfma(net.conv[2], Bf, A, n, 16, Wpad / 4, 0, true, nullptr, 0, s));         // (n,16,W/4,128)
+    OCR_TRY(launch_conv_mfma(net.conv[3], A, Bf, n, 16, Wpad / 4, 2, true, nullptr, 0, s));         // (n,8,W/4,128)
+    OCR_TRY(launch_conv_mfma(net.conv[4], Bf, A, n, 8, Wpad / 4, 0, true, nullptr, 0, s));          // (n,8,W/4,256)
+    OCR_TRY(launch_conv_mfma(net.conv[5], A, Bf, n, 8, Wpad / 4, 2, true, nullptr, 0, s));          // (n,4,W/4,256)
+    OCR_TRY(launch_conv_mfma(net.conv[6], Bf, A, n, 4, Wpad / 4, 0, true, nullptr, 0, s));          // (n,3,T,256)
+
+    const size_t nT = (size_t)n * T;
+    OCR_TRY(net.feats.reserve(nT * Hd * sizeof(float)));
+    OCR_TRY(net.xw.reserve(2 * nT * 4 * Hd * sizeof(float)));
+    OCR_TRY(net.hbuf.reserve((size_t)2 * 2 * n * Hd * sizeof(float)));
+    OCR_TRY(net.cbuf.reserve((size_t)2 * n * Hd * sizeof(float)));
+    OCR_TRY(net.seq.reserve(nT * 2 * Hd * sizeof(float)));
+    OCR_TRY(net.lin.reserve(2 * nT * Hd * sizeof(float)));
+    float* feats = net.feats.as<float>();
+    OCR_TRY(launch_mean_rows(A, feats, n, 3, T, Hd, s));
+    net.taps.clear();
+    record(net.taps, "features", feats, n, T, Hd, 1);
+
+    const float* layer_in = feats;
+    for (int l = 0; l < 2; ++l) {
+        float* xw_f = net.xw.as<float>();
+        float* xw_b = xw_f + nT * 4 * Hd;
+        OCR_TRY(launch_conv_mfma(net.wih[l][0], layer_in, xw_f, 1, 1, (int)nT, 0, false, nullptr, 0, s));
+        OCR_TRY(launch_conv_mfma(net.wih[l][1], layer_in, xw_b, 1, 1, (int)nT, 0, false, nullptr, 0, s));
+        float* hb0 = net.hbuf.as<float>();
+        float* hb1 = hb0 + (size_t)2 * n * Hd;
+        for (int step = 0; step < T; ++step) {
+            const float* hp = (step & 1) ? hb1 : hb0;
+            float* hn = (step & 1) ? hb0 : hb1;
+            OCR_TRY(launch_lstm_step(xw_f, xw_b, net.whh[l][0].as<float>(), net.whh[l][1].as<float>(), hp, hn,
+                                     net.cbuf.as<float>(), net.seq.as<float>(), n, T, step, s));
+        }
+        float* lin = net.lin.as<float>() + (size_t)l * nT * Hd;
+        OCR_TRY(launch_conv_mfma(net.linear[l], net.seq.as<float>(), lin, 1, 1, (int)nT, 0, false, nullptr, 0, s));
+        record(net.taps, l == 0 ? "seq0" : "seq1", lin, n, T, Hd, 1);
+        layer_in = lin;
+    }
+    float* logits = d_logits;
+    if (!logits) {
+        OCR_TRY(net.logits.reserve(nT * net.vocab * sizeof(float)));
+        logits = net.logits.as<float>();
+    }
+    OCR_TRY(launch_conv_mfma(net.pred, layer_in, logits, 1, 1, (int)nT, 0, false, nullptr, 0, s));
+    if (d_tokens) OCR_TRY(launch_ctc_greedy(logits, n, T, net.vocab, net.vocab, nullptr, 0, d_tokens, d_scores, s));
+    return OCRHIP_OK;
+}
+
+int ocrhip_crnn_get_activation(ocrhip_handle h, const char* name, float* dst, int64_t dst_capacity, int64_t shape[4]) {
+    OCR_HANDLE(h);
+    return read_activation(h->crnn.taps, name, dst, dst_capacity, shape);
+}
+
+int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int V, const int* d_lengths, int blank,
+                      int* d_tokens, float* d_scores, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    return launch_ctc_greedy(d_logits, B, T, V, V, d_lengths, blank, d_tokens, d_scores, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// Shared declarations of libocrhip.so (host side + launch helpers).  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ocrhip.h"
+
+namespace ocrhip {
+
+void set_error(const char* fmt, ...);
+
+#define OCR_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ocrhip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                              __LINE__);                                                      \
+            return OCRHIP_EHIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define OCR_REQUIRE(cond, ...)              \
+    do {                                    \
+        if (!(cond)) {                      \
+            ocrhip::set_error(__VA_ARGS__); \
+            return OCRHIP_EINVAL;           \
+        }                                   \
+    } while (0)
+
+#define OCR_TRY(expr)               \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != OCRHIP_OK) return _rc; \
+    } while (0)
+
+// Grow-only device buffer owned by a handle.
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need);
+    void release();
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+// One convolution / GEMM layer after batch-norm folding, in the device layouts the kernels read.
+struct ConvLayer {
+    int cin = 0, cout = 0, ks = 0;
+    int cout_pad = 0;       // cout rounded up to the kernel's N tile
+    DevBuf w_f32;           // MFMA slab layout (see conv_mfma.hip) or direct layout (see conv_direct.hip)
+    DevBuf bias;            // cout_pad floats, folded
+    bool direct = false;    // small-Cin direct kernel layout
+};
+
+struct Activation {
+    const float* ptr = nullptr;
+    int64_t shape[4] = {0, 0, 0, 0};
+};
+
+struct EastNet {
+    bool loaded = false;
+    ConvLayer vgg[13];
+    ConvLayer merge[7];
+    ConvLayer head;          // 32 -> 6 (score, 4 geo, angle), direct layout [6][32] + bias[6]
+    DevBuf act[2];           // ping-pong activations
+    DevBuf pool[5];          // pool1..pool5 taps (pool2..4 feed the merge branch)
+    std::map<std::string, Activation> taps;
+};
+
+struct LstmDir {
+    DevBuf w_ih;             // GEMM slab layout, 256 -> 1024
+    DevBuf bias;             // b_ih + b_hh, 1024
+    DevBuf w_hh;             // (1024,256) float32 as in the checkpoint
+};
+
+struct CrnnNet {
+    bool loaded = false;
+    int vocab = 0, vocab_pad = 0, hidden = 256;
+    ConvLayer conv[7];       // ConvNet.0,3,6,8,11,14,18
+    ConvLayer wih[2][2];     // [layer][dir] input projections 256 -> 1024 (bias = b_ih + b_hh)
+    DevBuf whh[2][2];        // [layer][dir] (1024,256) float32
+    ConvLayer linear[2];     // 512 -> 256
+    ConvLayer pred;          // 256 -> vocab
+    DevBuf act[2];
+    DevBuf feats, xw, hbuf, cbuf, seq, lin, logits;
+    std::map<std::string, Activation> taps;
+};
+
+}  // namespace ocrhip
+
+struct ocrhip_ctx {
+    int device = 0;
+    ocrhip::EastNet east;
+    ocrhip::CrnnNet crnn;
+    ocrhip::DevBuf decode_stage;   // staging of the decode kernel
+    ocrhip::DevBuf lanms_ws;       // scratch of the LANMS kernel
+};
+
+namespace ocrhip {
+
+// ---- kernels (one launcher per .hip file) -------------------------------------------------------
+
+// conv_mfma.hip: implicit-GEMM convolution on f32 MFMA, NHWC float32.
+//   ks 3 (pad 1), 2 (valid) or 1 (flat GEMM over B*H*W rows).
+//   pool: 0 none, 1 max 2x2, 2 max (2,1) (rows only) fused into the epilogue.
+//   up_src != nullptr: the first up_c input channels are the x2 align-corners bilinear upsampling of
+//   up_src (B,H/2,W/2,up_c) and the remaining cin - up_c channels come from x (B,H,W,cin-up_c).
+int prepare_conv_mfma(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);
+int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
+                     const float* up_src, int up_c, hipStream_t s);
+
+// conv_direct.hip: first layers (Cin 3 or 1) and the 32->6 sigmoid heads.
+int prepare_conv_direct(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);
+int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y, int B, int H, int W, int pool,
+                      hipStream_t s);
+int launch_east_heads(const ConvLayer& L, const float* x, float* maps, int64_t npix, hipStream_t s);
+
+// decode.hip
+int launch_east_decode(ocrhip_ctx* h, const float* maps, int B, int mh, int mw, int in_h, int in_w, float thr,
+                       int cap, float* xyxy, float* polys, float* scores, int* pix, int* counts, hipStream_t s);
+
+// lanms.hip
+int launch_lanms(ocrhip_ctx* h, const float* xyxy, const float* scores, const int* counts, int B, int cap,
+                 float merge_thr, float nms_thr, int merge_method, int max_iter, int max_out, float* merged,
+                 uint8_t* keep, float* out_boxes, float* out_scores, int* out_src, int* out_counts, int* n_iter,
+                 hipStream_t s);
+
+// crop.hip
+int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* rects, const int* box_img,
+                            const int* inter, const int* out_w, const int64_t* dst_off, int n, int out_h,
+                            void* packed, int out_dtype, hipStream_t s);
+
+// rnn.hip
+int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
+int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, const float* h_prev,
+                     float* h_next, float* c_state, float* out, int n, int T, int step, hipStream_t s);
+
+// ctc.hip
+int launch_ctc_greedy(const float* logits, int B, int T, int V, int ld_v, const int* lengths, int blank,
+                      int* tokens, float* scores, hipStream_t s);
+
+}  // namespace ocrhip

@@ -1,0 +1,186 @@
+// Direct (VALU) convolutions for the layers whose reduction depth is too small for the matrix
+// cores: the first 3x3 convolution of EAST (3 -> 64, fused with the `/255`, `(x-0.5)/0.5`
+// normalisation when the input is uint8), the first 3x3 convolution of the CRNN (1 -> 32, fused
+// with its 2x2 max-pool) and the three 1x1 sigmoid heads of EAST (32 -> 1 + 4 + 1).
+//
+// Restates architectures/east_arch.py:121-129,153-162, architectures/crnn_arch.py:38-41,459-473 and
+// utils/image/image_normalization.py:57 (+ utils/keras/ops/core.py:271).  All three are HBM bound:
+// the first EAST layer writes 256 B per input pixel, so outputs go through an LDS transpose and
+// leave as full 16-byte-per-lane coalesced rows.
+#include "common.h"
+
+namespace ocrhip {
+
+namespace {
+
+// One wave = 64 consecutive output pixels of one row; the 4 waves of a workgroup own COUT/4 output
+// channels each.  Weights are indexed by wave-uniform expressions, so they travel through scalar
+// registers.  Layout of w: [ky][kx][cin][cout].
+template <int CIN, int COUT, bool POOL, bool U8>
+__global__ __launch_bounds__(256) void conv_first_kernel(const void* __restrict__ xin, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int H, int W) {
+    constexpr int CPW = COUT / 4;               // channels per wave
+    constexpr int LDS_STRIDE = COUT + 4;
+    __shared__ float tile[64 * LDS_STRIDE];
+
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+    const int ox0 = blockIdx.x * 64, oy = blockIdx.y, b = blockIdx.z;
+    const int ox = ox0 + lane;
+
+    constexpr int P = POOL ? 2 : 1;             // pre-pool pixels per axis
+    constexpr int PATCH = P + 2;
+    float in[PATCH][PATCH][CIN];
+    const int iy0 = oy * P - 1, ix0 = ox * P - 1;
+#pragma unroll
+    for (int dy = 0; dy < PATCH; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < PATCH; ++dx) {
+            const int yy = iy0 + dy, xx = ix0 + dx;
+            const bool ok = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                float v = 0.0f;
+                if (ok) {
+                    const int64_t idx = (((int64_t)b * H + yy) * W + xx) * CIN + c;
+                    if (U8) {
+                        const float u = (float)reinterpret_cast<const uint8_t*>(xin)[idx];
+                        v = ((u / 255.0f) - 0.5f) / 0.5f;
+                    } else {
+                        v = reinterpret_cast<const float*>(xin)[idx];
+                    }
+                }
+                in[dy][dx][c] = v;
+            }
+        }
+    }
+
+    float acc[P][P][CPW];
+#pragma unroll
+    for (int py = 0; py < P; ++py)
+#pragma unroll
+        for (int px = 0; px < P; ++px)
+#pragma unroll
+            for (int o = 0; o < CPW; ++o) acc[py][px][o] = 0.0f;
+
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float* wp = w + ((ky * 3 + kx) * CIN + c) * COUT + g * CPW;
+#pragma unroll
+                for (int o = 0; o < CPW; ++o) {
+                    const float wv = wp[o];
+#pragma unroll
+                    for (int py = 0; py < P; ++py)
+#pragma unroll
+                        for (int px = 0; px < P; ++px)
+                            acc[py][px][o] = fmaf(in[py + ky][px + kx][c], wv, acc[py][px][o]);
+                }
+            }
+
+#pragma unroll
+    for (int o = 0; o < CPW; ++o) {
+        float v = acc[0][0][o];
+        if (POOL) v = fmaxf(fmaxf(v, acc[0][P - 1][o]), fmaxf(acc[P - 1][0][o], acc[P - 1][P - 1][o]));
+        v = fmaxf(v + bias[g * CPW + o], 0.0f);
+        tile[lane * LDS_STRIDE + g * CPW + o] = v;
+    }
+    __syncthreads();
+
+    // 64 pixels x COUT channels are contiguous in NHWC: store them as float4 rows
+    const int npx = min(64, Wo - ox0);
+    float* dst = y + (((int64_t)b * Ho + oy) * Wo + ox0) * COUT;
+    constexpr int V4_PER_PX = COUT / 4;
+    for (int i = threadIdx.x; i < npx * V4_PER_PX; i += 256) {
+        const int px = i / V4_PER_PX, c4 = i % V4_PER_PX;
+        const float4 v = *reinterpret_cast<const float4*>(&tile[px * LDS_STRIDE + c4 * 4]);
+        reinterpret_cast<float4*>(dst)[i] = v;
+    }
+}
+
+// 1x1 heads on the 32-channel merged map: out = sigmoid(W x + b), 6 channels.  w: [6][32].
+__global__ __launch_bounds__(256) void east_heads_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ maps,
+                                                         int64_t npix) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    float v[32];
+    const float4* xp = reinterpret_cast<const float4*>(x + p * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 q = xp[i];
+        v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    }
+    float out[6];
+#pragma unroll
+    for (int o = 0; o < 6; ++o) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc = fmaf(v[c], w[o * 32 + c], acc);
+        acc += bias[o];
+        out[o] = 1.0f / (1.0f + expf(-acc));
+    }
+    float2* op = reinterpret_cast<float2*>(maps + p * 6);
+    op[0] = make_float2(out[0], out[1]);
+    op[1] = make_float2(out[2], out[3]);
+    op[2] = make_float2(out[4], out[5]);
+}
+
+}  // namespace
+
+int prepare_conv_direct(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks) {
+    L.cin = cin; L.cout = cout; L.ks = ks; L.cout_pad = cout; L.direct = true;
+    std::vector<float> w((size_t)ks * ks * cin * cout);
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int ky = 0; ky < ks; ++ky)
+                for (int kx = 0; kx < ks; ++kx)
+                    w[((size_t)(ky * ks + kx) * cin + c) * cout + o] = w_oihw[(((size_t)o * cin + c) * ks + ky) * ks + kx];
+    OCR_TRY(L.w_f32.reserve(w.size() * sizeof(float)));
+    OCR_TRY(L.bias.reserve((size_t)cout * sizeof(float)));
+    OCR_HIP_CHECK(hipMemcpy(L.w_f32.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    OCR_HIP_CHECK(hipMemcpy(L.bias.ptr, bias, (size_t)cout * sizeof(float), hipMemcpyHostToDevice));
+    return OCRHIP_OK;
+}
+
+int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y, int B, int H, int W, int pool,
+                      hipStream_t s) {
+    OCR_REQUIRE(L.direct && L.ks == 3, "conv_first: layer is not a direct 3x3 layer");
+    OCR_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, "conv_first: bad sizes B=%d H=%d W=%d", B, H, W);
+    const float* w = L.w_f32.as<float>();
+    const float* bias = L.bias.as<float>();
+    if (L.cin == 3 && L.cout == 64 && pool == 0) {
+        dim3 grid((W + 63) / 64, H, B), block(256);
+        if (x_is_u8)
+            hipLaunchKernelGGL((conv_first_kernel<3, 64, false, true>), grid, block, 0, s, x, w, bias, y, H, W);
+        else
+            hipLaunchKernelGGL((conv_first_kernel<3, 64, false, false>), grid, block, 0, s, x, w, bias, y, H, W);
+    } else if (L.cin == 1 && L.cout == 32 && pool == 1 && !x_is_u8) {
+        OCR_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_first: pooled layer needs even H, W (got %dx%d)", H, W);
+        dim3 grid((W / 2 + 63) / 64, H / 2, B), block(256);
+        hipLaunchKernelGGL((conv_first_kernel<1, 32, true, false>), grid, block, 0, s, x, w, bias, y, H, W);
+    } else {
+        set_error("conv_first: unsupported configuration cin=%d cout=%d pool=%d u8=%d", L.cin, L.cout, pool, (int)x_is_u8);
+        return OCRHIP_EINVAL;
+    }
+    OCR_HIP_CHECK(hipGetLastError());
+    return OCRHIP_OK;
+}
+
+int launch_east_heads(const ConvLayer& L, const float* x, float* maps, int64_t npix, hipStream_t s) {
+    OCR_REQUIRE(L.cin == 32 && L.cout == 6, "east_heads: expected a 32 -> 6 layer");
+    if (npix <= 0) return OCRHIP_OK;
+    const int64_t blocks = (npix + 255) / 256;
+    OCR_REQUIRE(blocks < (1ll << 31), "east_heads: too many pixels");
+    hipLaunchKernelGGL(east_heads_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, L.w_f32.as<float>(),
+                       L.bias.as<float>(), maps, npix);
+    OCR_HIP_CHECK(hipGetLastError());
+    return OCRHIP_OK;
+}
+
+}  // namespace ocrhip

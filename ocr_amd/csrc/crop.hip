@@ -1,0 +1,158 @@
+// Crop -> /255 -> grayscale -> antialiased bilinear resize -> repeat-last pad -> (x-0.5)/0.5,
+// written straight into the packed recogniser batch.
+//
+// Restates utils/image/bounding_box/processing.py:128-132 (the slice), utils/image/image_io.py:126-135
+// (dtype, gray, resize), utils/image/image_processing.py:54-79,125-134 (resize to the intermediate size,
+// repeat_last padding) and utils/image/image_normalization.py:58.  The resize is the separable
+// triangle filter Keras' `image.resize(bilinear, antialias=True)` runs on its torch backend:
+// width first, then height, taps and weights in float32 with the index arithmetic of the filter
+// bounds in float64, each tap accumulated with a separate multiply and add (-ffp-contract=off).
+//
+// One output pixel per thread iteration; the horizontal sums of the rows a pixel needs are
+// recomputed instead of staged (2-5 taps per axis for text crops), so the kernel keeps no
+// per-crop state and has no size limit.  Bound by HBM/L2 gathers of the 3-byte source pixels:
+// algorithmic traffic = 3 B x crop pixels read + 4 (or 2) B x 64 x Wpad written.
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace ocrhip {
+
+namespace {
+
+struct Axis {
+    float scale, support, invscale;
+    int in, out;
+    bool identity;
+};
+
+__device__ __forceinline__ Axis make_axis(int in, int out) {
+    Axis a;
+    a.in = in;
+    a.out = out;
+    a.identity = (in == out);
+    a.scale = (float)in / (float)out;
+    a.support = (a.scale >= 1.0f) ? a.scale : 1.0f;
+    a.invscale = (a.scale >= 1.0f) ? (float)(1.0 / (double)a.scale) : 1.0f;
+    return a;
+}
+
+// first source index and tap count of output coordinate i
+__device__ __forceinline__ void tap_range(const Axis& a, int i, float& center, int& lo, int& cnt) {
+    center = (float)((double)a.scale * ((double)i + 0.5));
+    const long long l = (long long)((double)(center - a.support) + 0.5);
+    const long long h = (long long)((double)(center + a.support) + 0.5);
+    lo = (int)(l > 0 ? l : 0);
+    cnt = (int)(h < (long long)a.in ? h : (long long)a.in) - lo;
+}
+
+__device__ __forceinline__ float tap_weight(const Axis& a, float center, int lo, int j) {
+    float x = (float)(((double)((float)(j + lo) - center) + 0.5) * (double)a.invscale);
+    x = fabsf(x);
+    return (x < 1.0f) ? (1.0f - x) : 0.0f;
+}
+
+__device__ __forceinline__ float gray_at(const uint8_t* __restrict__ img, int W, int y, int x) {
+    const uint8_t* p = img + ((int64_t)y * W + x) * 3;
+    const float r = (float)p[0] / 255.0f, g = (float)p[1] / 255.0f, b = (float)p[2] / 255.0f;
+    float v = r * 0.2989f;
+    v = v + g * 0.5870f;
+    v = v + b * 0.1140f;
+    return v;
+}
+
+// horizontally resized gray value of source row y (crop coordinates) at resized column sx
+__device__ __forceinline__ float hsample(const uint8_t* __restrict__ img, int W, int x0, int yy, const Axis& ax,
+                                         int sx) {
+    if (ax.identity) return gray_at(img, W, yy, x0 + sx);
+    float center;
+    int lo, cnt;
+    tap_range(ax, sx, center, lo, cnt);
+    float total = 0.0f;
+    for (int j = 0; j < cnt; ++j) total = total + tap_weight(ax, center, lo, j);
+    float acc = 0.0f;
+    for (int j = 0; j < cnt; ++j) {
+        float w = tap_weight(ax, center, lo, j);
+        if (total != 0.0f) w = w / total;
+        const float term = gray_at(img, W, yy, x0 + lo + j) * w;
+        acc = (j == 0) ? term : (acc + term);
+    }
+    return acc;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void crop_resize_pack_kernel(const uint8_t* __restrict__ img, int B, int H, int W,
+                                                               const int* __restrict__ rects,
+                                                               const int* __restrict__ box_img,
+                                                               const int* __restrict__ inter,
+                                                               const int* __restrict__ out_w_arr,
+                                                               const int64_t* __restrict__ dst_off, int out_h,
+                                                               void* __restrict__ packed) {
+    const int n = blockIdx.x;
+    int b = box_img[n];
+    b = min(max(b, 0), B - 1);
+    // the rectangle is clamped to the image so that a bad rectangle can never read out of bounds
+    int x0 = min(max(rects[4 * n + 0], 0), W - 1), y0 = min(max(rects[4 * n + 1], 0), H - 1);
+    int x1 = min(max(rects[4 * n + 2], x0 + 1), W), y1 = min(max(rects[4 * n + 3], y0 + 1), H);
+    const int ch = y1 - y0, cw = x1 - x0;
+    const int out_w = out_w_arr[n];
+    const int ih = min(max(inter[2 * n + 0], 1), out_h), iw = min(max(inter[2 * n + 1], 1), out_w);
+    const uint8_t* src = img + (int64_t)b * H * W * 3;
+    const Axis ax = make_axis(cw, iw), ay = make_axis(ch, ih);
+    const int64_t dst = dst_off[n];
+
+    const int rows_per_block = (out_h + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(out_h, r0 + rows_per_block);
+    const int total = (r1 - r0) * out_w;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int oy = r0 + i / out_w, ox = i % out_w;
+        const int sy = min(oy, ih - 1), sx = min(ox, iw - 1);     // repeat_last: right, then bottom
+        float v;
+        if (ay.identity) {
+            v = hsample(src, W, x0, y0 + sy, ax, sx);
+        } else {
+            float center;
+            int lo, cnt;
+            tap_range(ay, sy, center, lo, cnt);
+            float total_w = 0.0f;
+            for (int j = 0; j < cnt; ++j) total_w = total_w + tap_weight(ay, center, lo, j);
+            v = 0.0f;
+            for (int j = 0; j < cnt; ++j) {
+                float w = tap_weight(ay, center, lo, j);
+                if (total_w != 0.0f) w = w / total_w;
+                const float term = hsample(src, W, x0, y0 + lo + j, ax, sx) * w;
+                v = (j == 0) ? term : (v + term);
+            }
+        }
+        v = (v - 0.5f) / 0.5f;
+        const int64_t o = dst + (int64_t)oy * out_w + ox;
+        if (BF16)
+            reinterpret_cast<__hip_bfloat16*>(packed)[o] = __float2bfloat16(v);
+        else
+            reinterpret_cast<float*>(packed)[o] = v;
+    }
+}
+
+}  // namespace
+
+int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* rects, const int* box_img,
+                            const int* inter, const int* out_w, const int64_t* dst_off, int n, int out_h,
+                            void* packed, int out_dtype, hipStream_t s) {
+    OCR_REQUIRE(img && rects && box_img && inter && out_w && dst_off && packed, "crop_resize_pack: null argument");
+    OCR_REQUIRE(B > 0 && H > 0 && W > 0 && n >= 0 && out_h > 0, "crop_resize_pack: bad sizes B=%d H=%d W=%d n=%d out_h=%d",
+                B, H, W, n, out_h);
+    OCR_REQUIRE(out_dtype == OCRHIP_F32 || out_dtype == OCRHIP_BF16, "crop_resize_pack: out_dtype must be F32 or BF16");
+    if (n == 0) return OCRHIP_OK;
+    dim3 grid(n, 4), block(256);
+    if (out_dtype == OCRHIP_BF16)
+        hipLaunchKernelGGL(crop_resize_pack_kernel<true>, grid, block, 0, s, img, B, H, W, rects, box_img, inter, out_w,
+                           dst_off, out_h, packed);
+    else
+        hipLaunchKernelGGL(crop_resize_pack_kernel<false>, grid, block, 0, s, img, B, H, W, rects, box_img, inter, out_w,
+                           dst_off, out_h, packed);
+    OCR_HIP_CHECK(hipGetLastError());
+    return OCRHIP_OK;
+}
+
+}  // namespace ocrhip

@@ -1,0 +1,201 @@
+"""Thin host layer over the C ABI: torch tensors in, torch tensors out.
+
+PyTorch is used for device memory and streams only; every computation below happens inside
+libocrhip.so.  One `HipContext` per (device, host thread).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, U8, MERGE_UNION, MERGE_AVERAGE, TensorDesc, check
+
+_MERGE = {'union': MERGE_UNION, 'average': MERGE_AVERAGE}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _descs(state_dict):
+    """state dict (torch tensors or arrays) -> (ctypes array of TensorDesc, keep-alive list)."""
+    keep, items = [], []
+    for name, value in state_dict.items():
+        if name.startswith('module.'):
+            name = name[len('module.'):]
+        if name.endswith('num_batches_tracked'):
+            continue
+        arr = value.detach().cpu().numpy() if isinstance(value, torch.Tensor) else np.asarray(value)
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        if arr.ndim > 4:
+            continue
+        bname = name.encode('utf-8')
+        keep.append((arr, bname))
+        d = TensorDesc()
+        d.name = bname
+        d.data = arr.ctypes.data
+        d.ndim = arr.ndim
+        for i in range(arr.ndim):
+            d.shape[i] = arr.shape[i]
+        items.append(d)
+    array = (TensorDesc * len(items))(*items)
+    return array, keep
+
+
+class HipContext:
+    """Owns one ocrhip handle (weights + workspaces) on one GPU."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError('ocr_amd needs a ROCm GPU (torch.cuda.is_available() is False)')
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', device)
+        h = ctypes.c_void_p()
+        check(self.lib.ocrhip_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.east_loaded = False
+        self.crnn_loaded = False
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.ocrhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ EAST
+    def east_load_weights(self, state_dict):
+        arr, keep = _descs(state_dict)
+        check(self.lib.ocrhip_east_load_weights(self._h, arr, len(arr)))
+        self.east_loaded = True
+
+    def east_forward(self, images, compute_dtype=F32):
+        """images: (B,H,W,3) uint8 raw or float32 normalised, on the GPU -> (B,H/4,W/4,6) float32."""
+        assert images.is_cuda and images.dim() == 4 and images.shape[3] == 3 and images.is_contiguous()
+        if images.dtype == torch.uint8:
+            in_dtype = U8
+        elif images.dtype == torch.float32:
+            in_dtype = F32
+        else:
+            raise ValueError('east_forward: images must be uint8 or float32')
+        B, H, W, _ = images.shape
+        maps = torch.empty((B, H // 4, W // 4, 6), dtype=torch.float32, device=images.device)
+        check(self.lib.ocrhip_east_forward(self._h, _ptr(images), B, H, W, in_dtype, compute_dtype, _ptr(maps), _stream()))
+        return maps
+
+    def _activation(self, fn, name):
+        shape = (ctypes.c_int64 * 4)()
+        check(fn(self._h, name.encode(), None, 0, shape))
+        out = np.empty(tuple(int(s) for s in shape), dtype=np.float32)
+        check(fn(self._h, name.encode(), out.ctypes.data, out.size, shape))
+        return out
+
+    def east_activation(self, name):
+        return self._activation(self.lib.ocrhip_east_get_activation, name)
+
+    def east_decode(self, maps, input_hw, threshold=0.35, cap=None, with_polys=False, with_pix=False):
+        """maps (B,mh,mw,6) -> dict(xyxy (B,cap,4), scores (B,cap), counts (B,), [polys (B,cap,4,2)], [pix])."""
+        assert maps.is_cuda and maps.dtype == torch.float32 and maps.is_contiguous()
+        B, mh, mw, _ = maps.shape
+        if cap is None:
+            cap = mh * mw
+        dev = maps.device
+        out = {
+            'xyxy': torch.empty((B, cap, 4), dtype=torch.float32, device=dev),
+            'scores': torch.empty((B, cap), dtype=torch.float32, device=dev),
+            'counts': torch.empty((B,), dtype=torch.int32, device=dev),
+        }
+        polys = torch.empty((B, cap, 4, 2), dtype=torch.float32, device=dev) if with_polys else None
+        pix = torch.empty((B, cap), dtype=torch.int32, device=dev) if with_pix else None
+        check(self.lib.ocrhip_east_decode(self._h, _ptr(maps), B, mh, mw, int(input_hw[0]), int(input_hw[1]),
+                                          float(threshold), int(cap), _ptr(out['xyxy']), _ptr(polys),
+                                          _ptr(out['scores']), _ptr(pix), _ptr(out['counts']), _stream()))
+        if with_polys:
+            out['polys'] = polys
+        if with_pix:
+            out['pix'] = pix
+        return out
+
+    def lanms(self, xyxy, scores, counts, merge_threshold=0.3, nms_threshold=0.25, merge_method='union',
+              max_iter=0, max_out=0, full=False):
+        """xyxy (B,cap,4), scores (B,cap) or None, counts (B,) int32 ->
+        dict(boxes (B,cap,4) rank order, scores, src, counts, n_iter, [merged, keep in input order])."""
+        assert xyxy.is_cuda and xyxy.dtype == torch.float32 and xyxy.is_contiguous()
+        B, cap, _ = xyxy.shape
+        dev = xyxy.device
+        out = {
+            'boxes': torch.empty((B, cap, 4), dtype=torch.float32, device=dev),
+            'scores': torch.empty((B, cap), dtype=torch.float32, device=dev),
+            'src': torch.empty((B, cap), dtype=torch.int32, device=dev),
+            'counts': torch.empty((B,), dtype=torch.int32, device=dev),
+            'n_iter': torch.empty((B,), dtype=torch.int32, device=dev),
+        }
+        merged = torch.empty((B, cap, 4), dtype=torch.float32, device=dev) if full else None
+        keep = torch.empty((B, cap), dtype=torch.uint8, device=dev) if full else None
+        check(self.lib.ocrhip_lanms(self._h, _ptr(xyxy), _ptr(scores), _ptr(counts), B, cap, float(merge_threshold),
+                                    float(nms_threshold), _MERGE[merge_method], int(max_iter or 0), int(max_out or 0),
+                                    _ptr(merged), _ptr(keep), _ptr(out['boxes']), _ptr(out['scores']), _ptr(out['src']),
+                                    _ptr(out['counts']), _ptr(out['n_iter']), _stream()))
+        if full:
+            out['merged'], out['keep'] = merged, keep
+        return out
+
+    # ------------------------------------------------------------------ crop / pack
+    def crop_resize_pack(self, images, rects, box_img, inter_hw, out_w, dst_off, total_elems, out_h=64,
+                         out_dtype=torch.float32):
+        """images (B,H,W,3) uint8; rects (n,4) int32; box_img (n,) int32; inter_hw (n,2) int32; out_w (n,) int32;
+        dst_off (n,) int64 -> flat packed buffer of `total_elems` elements."""
+        assert images.is_cuda and images.dtype == torch.uint8 and images.is_contiguous()
+        B, H, W, _ = images.shape
+        n = int(rects.shape[0])
+        packed = torch.empty((int(total_elems),), dtype=out_dtype, device=images.device)
+        code = F32 if out_dtype == torch.float32 else BF16
+        check(self.lib.ocrhip_crop_resize_pack(self._h, _ptr(images), B, H, W, _ptr(rects), _ptr(box_img), _ptr(inter_hw),
+                                               _ptr(out_w), _ptr(dst_off), n, int(out_h), _ptr(packed), code, _stream()))
+        return packed
+
+    # ------------------------------------------------------------------ CRNN
+    def crnn_load_weights(self, state_dict):
+        arr, keep = _descs(state_dict)
+        check(self.lib.ocrhip_crnn_load_weights(self._h, arr, len(arr)))
+        self.crnn_loaded = True
+
+    @property
+    def vocab_size(self):
+        return int(self.lib.ocrhip_crnn_vocab_size(self._h))
+
+    def crnn_forward(self, crops, want_logits=True, want_tokens=False, compute_dtype=F32):
+        """crops (n,64,Wpad,1) or (n,64,Wpad) float32 -> dict(logits (n,T,V), tokens (n,T), scores (n,))."""
+        assert crops.is_cuda and crops.dtype == torch.float32 and crops.is_contiguous()
+        n, hh, Wpad = int(crops.shape[0]), int(crops.shape[1]), int(crops.shape[2])
+        if hh != 64:
+            raise ValueError('crnn_forward: crops must be 64 pixels high')
+        T, V = Wpad // 4 - 1, self.vocab_size
+        dev = crops.device
+        logits = torch.empty((n, T, V), dtype=torch.float32, device=dev) if want_logits else None
+        tokens = torch.empty((n, T), dtype=torch.int32, device=dev) if want_tokens else None
+        scores = torch.empty((n,), dtype=torch.float32, device=dev) if want_tokens else None
+        check(self.lib.ocrhip_crnn_forward(self._h, _ptr(crops), n, Wpad, compute_dtype, _ptr(logits), _ptr(tokens),
+                                           _ptr(scores), _stream()))
+        return {'logits': logits, 'tokens': tokens, 'scores': scores}
+
+    def crnn_activation(self, name):
+        return self._activation(self.lib.ocrhip_crnn_get_activation, name)
+
+    def ctc_greedy(self, logits, lengths=None, blank=0):
+        assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous()
+        B, T, V = logits.shape
+        tokens = torch.empty((B, T), dtype=torch.int32, device=logits.device)
+        scores = torch.empty((B,), dtype=torch.float32, device=logits.device)
+        check(self.lib.ocrhip_ctc_greedy(self._h, _ptr(logits), B, T, V, _ptr(lengths), int(blank), _ptr(tokens),
+                                         _ptr(scores), _stream()))
+        return tokens, scores

@@ -88,19 +88,20 @@ def aa_weights(in_size, out_size):
     Returns (xmin int array, list of float32 weight arrays).  The filter support widens with the
     down-scaling factor; when up-scaling it is the plain 2-tap bilinear kernel.
     """
-    f32 = np.float32
+    f32, f64 = np.float32, np.float64
     scale = f32(in_size) / f32(out_size)
-    support = f32(1.0) * scale if scale >= 1.0 else f32(1.0)
-    invscale = f32(1.0) / scale if scale >= 1.0 else f32(1.0)
+    support = scale if scale >= 1.0 else f32(1.0)
+    invscale = f32(1.0 / f64(scale)) if scale >= 1.0 else f32(1.0)
     xmins, weights = [], []
     for i in range(out_size):
-        center = scale * (f32(i) + f32(0.5))
-        xmin = max(int(center - support + f32(0.5)), 0)
-        xsize = min(int(center + support + f32(0.5)), in_size) - xmin
+        # float32 values, but the "+ 0.5" of the bounds and of the filter argument is done in float64
+        center = f32(f64(scale) * (i + 0.5))
+        xmin = max(int(f64(f32(center - support)) + 0.5), 0)
+        xsize = min(int(f64(f32(center + support)) + 0.5), in_size) - xmin
         ws = np.zeros(xsize, dtype=np.float32)
         total = f32(0.0)
         for j in range(xsize):
-            x = abs((f32(j + xmin) - center + f32(0.5)) * invscale)
+            x = abs(f32((f64(f32(f32(j + xmin) - center)) + 0.5) * f64(invscale)))
             w = f32(1.0) - x if x < 1.0 else f32(0.0)
             ws[j] = w
             total = total + w
