@@ -1,0 +1,77 @@
+"""Host-side size arithmetic of the image preparation, with the reference's dtypes.
+
+The kernels take sizes as arguments; they are computed here exactly as the reference computes
+them (`get_output_size`, utils/image/image_processing.py:144-213; the intermediate size of
+`resize_image`, :68-72; `normalize_boxes(..., 'absolute')`, utils/image/bounding_box/converter.py:
+186-196; the slice of `crop_box`, processing.py:128-132).
+"""
+import numpy as np
+
+
+def east_input_size(h, w, multiple=32):
+    """Each side rounded up to the next multiple (the image is stretched, not padded)."""
+    def up(v):
+        return v if v % multiple == 0 else (v // multiple + 1) * multiple
+    return up(int(h)), up(int(w))
+
+
+def crnn_output_size(crop_h, crop_w, height=64, multiple=64):
+    """Padded network input size for a crop: (height, W') with W' = int(w * height / h) rounded up
+    to the next multiple.  The ratio is taken in float64 like the reference (int / int division)."""
+    ratio = max(float(height) / float(crop_h), -1.0 / float(crop_w))
+    w_out = int(np.int32(np.float64(crop_w) * np.float64(ratio)))
+    if w_out % multiple != 0:
+        w_out = (w_out // multiple + 1) * multiple
+    return int(height), int(w_out)
+
+
+def crnn_intermediate_size(crop_h, crop_w, out_h, out_w):
+    """Size the crop is resized to before padding: int32(float32(hw) * min(float32(out) / float32(hw)))."""
+    img = np.array([crop_h, crop_w], dtype=np.float32)
+    ratio = np.min(np.array([out_h, out_w], dtype=np.float32) / img)
+    inter = (img * ratio).astype(np.int32)
+    return int(inter[0]), int(inter[1])
+
+
+def relative_to_absolute(boxes_rel, image_h, image_w):
+    """float32 relative xyxy -> int32 absolute, truncation toward zero of the float32 product."""
+    boxes_rel = np.asarray(boxes_rel, dtype=np.float32).reshape(-1, 4)
+    factors = np.array([image_w, image_h, image_w, image_h], dtype=np.float32)
+    return (boxes_rel * factors).astype(np.int32)
+
+
+def resolve_slices(abs_boxes, image_h, image_w):
+    """What `image[y0:y1, x0:x1]` selects for int boxes: (n,4) resolved x0,y0,x1,y1 and a validity
+    mask (False = empty crop, which the reference warns about and skips, models/ocr/base_ocr.py:182-184).
+    Negative indices wrap around as in NumPy."""
+    abs_boxes = np.asarray(abs_boxes).reshape(-1, 4)
+    out = np.zeros((len(abs_boxes), 4), dtype=np.int32)
+    valid = np.zeros((len(abs_boxes),), dtype=bool)
+    for i, (x0, y0, x1, y1) in enumerate(abs_boxes.tolist()):
+        xl, xh, _ = slice(x0, x1).indices(image_w)
+        yl, yh, _ = slice(y0, y1).indices(image_h)
+        out[i] = (xl, yl, max(xl, xh), max(yl, yh))
+        valid[i] = (xh > xl) and (yh > yl)
+    return out, valid
+
+
+def plan_crops(boxes_rel, image_h, image_w, height=64, multiple=64):
+    """Everything the crop kernel needs for the boxes of one image.
+
+    Returns dict(rects (m,4) int32, inter (m,2) int32, out_w (m,) int32, index (m,) indices of the
+    boxes that give a non-empty network input)."""
+    rects, valid = resolve_slices(relative_to_absolute(boxes_rel, image_h, image_w), image_h, image_w)
+    keep, inter, out_w = [], [], []
+    for i in np.nonzero(valid)[0]:
+        ch, cw = int(rects[i, 3] - rects[i, 1]), int(rects[i, 2] - rects[i, 0])
+        oh, ow = crnn_output_size(ch, cw, height, multiple)
+        if ow <= 0:
+            continue
+        ih, iw = crnn_intermediate_size(ch, cw, oh, ow)
+        if ih <= 0 or iw <= 0:
+            continue
+        keep.append(i), inter.append((ih, iw)), out_w.append(ow)
+    keep = np.array(keep, dtype=np.int64)
+    return {'rects': rects[keep].astype(np.int32).reshape(-1, 4),
+            'inter': np.array(inter, dtype=np.int32).reshape(-1, 2),
+            'out_w': np.array(out_w, dtype=np.int32), 'index': keep}

@@ -1,0 +1,71 @@
+"""GPU parity of the two networks (f32 MFMA path) against the torch-CPU float32 oracle, through the
+C ABI.  Tolerance: 1e-4 relative on the maps / logits (different summation order, same precision)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+from oracle import image as oimg, nets  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from ocr_amd.engine import HipContext
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+def _close(got, ref, rtol=1e-4, atol=2e-5):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = np.abs(got - ref)
+    tol = atol + rtol * np.abs(ref)
+    bad = err > tol
+    assert not bad.any(), 'max err %.3e (ref scale %.3e), %d / %d out of tolerance' % (
+        err.max(), np.abs(ref).max(), int(bad.sum()), bad.size)
+
+
+@pytest.mark.parametrize('B,H,W', [(1, 64, 96), (2, 128, 64)])
+def test_east_forward_matches_oracle(ctx, B, H, W):
+    params = nets.init_east_params(seed=1)
+    assert nets.count_params(params) == 15098726          # "15.099 M" in the reference notebook
+    ctx.east_load_weights(params)
+    rng = np.random.default_rng(B * 100 + H)
+    img = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    x = np.stack([oimg.prepare_east_input(i) for i in img])
+    ref, taps, merged = nets.east_forward(params, x, return_taps=True)
+    for in_t in (torch.from_numpy(img).cuda(), torch.from_numpy(x).cuda()):
+        maps = ctx.east_forward(in_t)
+        torch.cuda.synchronize()
+        for i in range(5):
+            # activations grow with depth under random weights: compare relative to their scale
+            t = taps[i].numpy()
+            _close(ctx.east_activation('pool%d' % (i + 1)), t, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(t).max())))
+        m = merged.numpy()
+        _close(ctx.east_activation('merge7'), m, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(m).max())))
+        _close(maps.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('n,Wpad,V', [(3, 128, 97), (2, 64, 97), (33, 192, 211)])
+def test_crnn_forward_matches_oracle(ctx, n, Wpad, V):
+    params = nets.init_crnn_params(vocab_size=V, seed=2)
+    ctx.crnn_load_weights(params)
+    assert ctx.vocab_size == V
+    rng = np.random.default_rng(n + Wpad)
+    x = rng.uniform(-1, 1, (n, 64, Wpad, 1)).astype(np.float32)
+    feats = nets.crnn_features(params, x)
+    ref = nets.crnn_forward(params, x).numpy()
+    out = ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True, want_tokens=True)
+    torch.cuda.synchronize()
+    f = feats.numpy()
+    _close(ctx.crnn_activation('features').reshape(f.shape), f, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(f).max())))
+    got = out['logits'].cpu().numpy()
+    _close(got, ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+    # greedy decode of the GPU logits, on the GPU, equals the oracle decode of the same logits
+    from oracle import ctc as octc
+    rt, rs = octc.ctc_greedy(got, None, 0)
+    np.testing.assert_array_equal(out['tokens'].cpu().numpy(), rt)
+    np.testing.assert_array_equal(out['scores'].cpu().numpy(), rs)
