@@ -1,0 +1,57 @@
+"""Reference-faithful CPU pipeline (test infrastructure and the timed CPU baseline of bench.py).
+
+Does what `BaseOCR.infer(image, combine=False, method='greedy')` does in the reference
+(models/ocr/base_ocr.py:146-247 on top of models/detection/base_detector.py:72-81 and
+models/detection/east.py:64-95): one EAST forward per image, NumPy decode, LANMS, then ONE
+recogniser forward PER TEXT ROW at batch 1, logits padded with 0 and decoded greedily.
+"""
+import numpy as np
+
+from . import boxes as obox, ctc as octc, east_decode, image as oimg, lanms_c, nets
+
+
+def detect_page(image_u8, east_params, maps_override=None, obj_threshold=0.35, nms_threshold=0.2,
+                merge_threshold=0.3, merge_method='union', trig='rounded64', run_network=True):
+    h, w = image_u8.shape[:2]
+    maps = None
+    if run_network:
+        x = oimg.prepare_east_input(image_u8)
+        maps = nets.east_forward(east_params, x[None])[0].numpy()
+        in_hw = x.shape[:2]
+    else:
+        in_hw = oimg.east_size(h, w)
+    used = maps if maps_override is None else maps_override
+    dec = east_decode.decode_map(used, in_hw, threshold=obj_threshold, trig=trig)
+    xyxy = obox.poly_to_xyxy(dec['boxes'])
+    if len(xyxy) == 0:
+        return maps, np.zeros((0, 4), np.float32), np.zeros((0,), np.float32)
+    boxes, scores, mask, _, _ = lanms_c.lanms(xyxy, dec['scores'], None, nms_threshold,
+                                              merge_threshold=merge_threshold, merge_method=merge_method)
+    return maps, boxes[mask], scores[mask]
+
+
+def recognise_rows(image_u8, boxes_rel, crnn_params, tokenizer):
+    """One forward per row (batch 1), as base_ocr.py:171-201; empty inputs are skipped (:182-184)."""
+    outputs, index = [], []
+    for i, box in enumerate(boxes_rel):
+        _, crop = obox.crop_box(image_u8, box)
+        inp = oimg.prepare_crnn_input(crop)
+        if inp is None or any(s == 0 for s in inp.shape):
+            continue
+        outputs.append(nets.crnn_forward(crnn_params, inp[None])[0].numpy())
+        index.append(i)
+    if not outputs:
+        return [], [], np.zeros((0,), np.float32)
+    lengths = np.array([len(o) for o in outputs], dtype=np.int32)
+    tmax, v = int(lengths.max()), outputs[0].shape[1]
+    padded = np.zeros((len(outputs), tmax, v), dtype=np.float32)      # pad_batch(pad_value=0.)
+    for k, o in enumerate(outputs):
+        padded[k, :len(o)] = o
+    texts, scores = tokenizer.ctc_decode(padded, lengths)
+    return index, texts, scores
+
+
+def ocr_page(image_u8, east_params, crnn_params, tokenizer, maps_override=None, **kw):
+    _, boxes, _ = detect_page(image_u8, east_params, maps_override, **kw)
+    index, texts, scores = recognise_rows(image_u8, boxes, crnn_params, tokenizer)
+    return {'boxes': boxes, 'index': index, 'texts': texts, 'scores': scores}
