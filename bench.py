@@ -1,0 +1,151 @@
+"""End-to-end OCR throughput on synthetic 1024x1024 dense-text pages (BASELINE.json config 4).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over a batch of pages already resident in HBM:
+EAST-VGG16 forward (f32 MFMA) -> RBOX decode -> LANMS + NMS -> crop/resize/pack -> CRNN + CTC greedy
+-> strings on the host.  Images are independent, so ranks share nothing (weak scaling, no
+collective in the data path; one barrier + one MAX all-reduce bracket the timed region).
+
+No trained weights exist offline: both networks run with seeded random weights of the reference
+architectures (all their arithmetic is executed and timed), and the decode stage consumes the
+synthetic "teacher" maps of the rendered pages instead of the random-weight network output, so that
+decode / LANMS / crop / CRNN see realistic box counts (~18 000 candidates and ~200 words per page).
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the 3x3 f32-MFMA
+convolution), timed with HIP events on the launch stream inside the timed region by the library's
+stage timers; `cpu_baseline` times the reference-faithful CPU path (oracle/) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense f32 matrix peak (= f32 vector peak)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=8, help='pages per step and per GPU')
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--words', type=int, default=220)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-pages', type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(images, maps, east_params, crnn_params, n_pages):
+    """Reference-faithful CPU path on a bounded sample (same pages as the GPU run)."""
+    from oracle import ctc as octc, pipeline as opipe
+    from ocr_amd.utils.text import ENGLISH_G2_CHARACTERS
+    tok = octc.CharTokenizer(ENGLISH_G2_CHARACTERS)
+    t0 = time.perf_counter()
+    words = 0
+    for b in range(n_pages):
+        res = opipe.ocr_page(images[b], east_params, crnn_params, tok, maps_override=maps[b], trig='numpy32')
+        words += len(res['texts'])
+    dt = time.perf_counter() - t0
+    return {'value': n_pages / dt, 'unit': 'images/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'words_per_s': words / dt,
+            'sample': '%d page(s) %dx%d of the GPU workload through oracle/pipeline.py: batch-1 EAST (torch-CPU f32), '
+                      'NumPy decode, C LANMS (1 thread), one CRNN forward per text row; %.1f s'
+                      % (n_pages, images.shape[1], images.shape[2], dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from ocr_amd import synth
+    from ocr_amd.pipeline import OcrPipeline
+    from ocr_amd.weights import random_east_params, random_crnn_params
+
+    east_params = random_east_params(seed=1)
+    crnn_params = random_crnn_params(vocab_size=97, seed=2)
+    pipe = OcrPipeline(east_params, crnn_params, device=local_rank)
+
+    B, S = args.batch, args.size
+    images, maps, _ = synth.make_pages(1234 + 4 + 100 * rank, B, S, S, args.words)
+    d_img = torch.from_numpy(images).cuda()
+    d_maps = torch.from_numpy(maps).cuda()
+
+    def step():
+        out = pipe(d_img, maps_override=d_maps)
+        return sum(int(o['valid'].sum()) for o in out), sum(len(o['boxes']) for o in out)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    words = boxes = 0
+    for _ in range(args.warmup):
+        words, boxes = step()
+    pipe.ctx.profile_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        words, boxes = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stats = pipe.ctx.profile_collect()
+    pipe.ctx.profile_enable(False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    if dist is not None:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        pages = world * args.steps * B
+        mfma = [s for s in stats if s['flops'] > 0 and s['name'].startswith('conv_mfma')]
+        dom = max(mfma, key=lambda s: s['total_ms'])
+        achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+        gpu_ms = sum(s['total_ms'] for s in stats)
+        conv_ms = sum(s['total_ms'] for s in mfma)
+        conv_tflops = sum(s['flops'] for s in mfma) / (conv_ms * 1e-3) / 1e12
+        line = {
+            'metric': 'end-to-end OCR images/sec (1024x1024 page)', 'value': pages / elapsed, 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[3]: full EAST->crop->CRNN pipeline on synthetic %dx%d dense-text pages' % (S, S),
+                       'pages_per_step_per_gpu': B, 'words_per_page': words / B, 'decode_candidates_per_page': None,
+                       'detector_maps': 'teacher maps of the rendered pages feed decode; the random-weight EAST forward '
+                                        'runs and is timed', 'parallelism': 'image-sharded x%d' % world},
+            'words_per_s': world * args.steps * words / elapsed,
+            'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'launches': dom['launches'],
+                         'avg_ms': dom['total_ms'] / dom['launches'], 'achieved': achieved,
+                         'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
+                         'traffic': None},
+            'gpu_time': {'kernels_ms_per_step': gpu_ms / args.steps, 'all_mfma_conv_tflops': conv_tflops,
+                         'stages_ms_per_step': {s['name']: round(s['total_ms'] / args.steps, 3) for s in stats}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(images, maps, east_params, crnn_params, min(args.cpu_pages, B))
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

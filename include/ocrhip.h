@@ -178,6 +178,26 @@ int ocrhip_crnn_get_activation(ocrhip_handle h, const char* name, float* dst, in
 int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int V, const int* d_lengths,
                       int blank, int* d_tokens, float* d_scores, ocrhip_stream stream);
 
+/* ------------------------------------------------------------------------------ stage timers --
+ * Per-kernel device timing with HIP events recorded on the caller's stream around every launch the
+ * library makes.  Replaces the hierarchical @timer / Timer instrumentation that wraps every stage of
+ * the reference (loggers/time_logging.py:27-136, e.g. models/detection/east.py:64,102,153).
+ *   ocrhip_profile_enable : enable != 0 starts recording (and drops earlier records), 0 stops
+ *   ocrhip_profile_collect: synchronises the device, aggregates the records per kernel name, writes
+ *                           at most `cap` entries sorted by total time and sets *n to the number of
+ *                           distinct kernels; flops / bytes are the ALGORITHMIC work of the launches
+ *                           (see DESIGN.md), not counter readings. */
+typedef struct {
+    char name[64];
+    int launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} ocrhip_kernel_stat;
+
+int ocrhip_profile_enable(ocrhip_handle h, int enable);
+int ocrhip_profile_collect(ocrhip_handle h, ocrhip_kernel_stat* out, int cap, int* n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,11 @@ class TensorDesc(ctypes.Structure):
     _fields_ = [('name', c_char_p), ('data', c_void_p), ('ndim', c_int), ('shape', c_int64 * 4)]
 
 
+class KernelStat(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char * 64), ('launches', c_int), ('total_ms', ctypes.c_double),
+                ('flops', ctypes.c_double), ('bytes', ctypes.c_double)]
+
+
 # name -> (restype, argtypes); every symbol of include/ocrhip.h
 SIGNATURES = {
     'ocrhip_version': (c_int, []),
@@ -41,6 +46,8 @@ SIGNATURES = {
     'ocrhip_crnn_get_activation': (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64)]),
     'ocrhip_ctc_greedy': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                   c_void_p]),
+    'ocrhip_profile_enable': (c_int, [c_void_p, c_int]),
+    'ocrhip_profile_collect': (c_int, [c_void_p, ctypes.POINTER(KernelStat), c_int, ctypes.POINTER(c_int)]),
 }
 
 _lib = None
@@ -51,6 +58,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # The library shares the process with PyTorch-ROCm (its tensors and streams are passed in), so
+    # both must run on ONE HIP runtime: import torch first, the loader then binds libocrhip.so to
+    # the libamdhip64 torch has already loaded.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             'libocrhip.so not found at {}.  Build it with `python -m ocr_amd.csrc.build` '

@@ -2,6 +2,7 @@
 // the two network graphs.  The graphs follow architectures/east_arch.py:95-175 and
 // architectures/crnn_arch.py:38-41,306-328,427-531 layer by layer; each layer is one launch of a
 // kernel from conv_direct.hip / conv_mfma.hip / rnn.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -16,6 +17,53 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_error, sizeof(g_error), fmt, ap);
     va_end(ap);
+}
+
+static thread_local Profiler* g_prof = nullptr;
+Profiler* current_profiler() { return g_prof; }
+void set_current_profiler(Profiler* p) { g_prof = p; }
+
+hipEvent_t Profiler::get_event() {
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void Profiler::recycle() {
+    for (auto& r : records) {
+        if (r.e0) pool.push_back(r.e0);
+        if (r.e1) pool.push_back(r.e1);
+    }
+    records.clear();
+}
+
+ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : p(current_profiler()), s(stream), idx(0) {
+    if (!p || !p->enabled) {
+        p = nullptr;
+        return;
+    }
+    ProfRecord r;
+    r.name = name;
+    r.flops = flops;
+    r.bytes = bytes;
+    r.e0 = p->get_event();
+    r.e1 = p->get_event();
+    if (!r.e0 || !r.e1) {
+        p = nullptr;
+        return;
+    }
+    (void)hipEventRecord(r.e0, s);
+    idx = p->records.size();
+    p->records.push_back(r);
+}
+
+ProfScope::~ProfScope() {
+    if (p) (void)hipEventRecord(p->records[idx].e1, s);
 }
 
 int DevBuf::reserve(size_t need) {
@@ -146,6 +194,7 @@ using namespace ocrhip;
             return OCRHIP_EINVAL;                                   \
         }                                                           \
         OCR_HIP_CHECK(hipSetDevice((h)->device));                   \
+        ocrhip::set_current_profiler(&(h)->prof);                   \
     } while (0)
 
 extern "C" {
@@ -196,6 +245,9 @@ int ocrhip_destroy(ocrhip_handle h) {
         b->release();
     h->decode_stage.release();
     h->lanms_ws.release();
+    h->prof.recycle();
+    for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
+    ocrhip::set_current_profiler(nullptr);
     delete h;
     return OCRHIP_OK;
 }
@@ -459,11 +511,16 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
         OCR_TRY(launch_conv_mfma(net.wih[l][1], layer_in, xw_b, 1, 1, (int)nT, 0, false, nullptr, 0, s));
         float* hb0 = net.hbuf.as<float>();
         float* hb1 = hb0 + (size_t)2 * n * Hd;
+        {
+        // one timer scope for the whole recurrence of a layer (T launches, both directions each)
+        ProfScope prof("lstm_layer(T steps)", 2.0 * 2 * (double)n * 4.0 * Hd * Hd * (T - 1),
+                       4.0 * (2.0 * nT * 4 * Hd + nT * 2 * Hd) + 4.0 * 2 * 4 * Hd * Hd * T, s);
         for (int step = 0; step < T; ++step) {
             const float* hp = (step & 1) ? hb1 : hb0;
             float* hn = (step & 1) ? hb0 : hb1;
             OCR_TRY(launch_lstm_step(xw_f, xw_b, net.whh[l][0].as<float>(), net.whh[l][1].as<float>(), hp, hn,
                                      net.cbuf.as<float>(), net.seq.as<float>(), n, T, step, s));
+        }
         }
         float* lin = net.lin.as<float>() + (size_t)l * nT * Hd;
         OCR_TRY(launch_conv_mfma(net.linear[l], net.seq.as<float>(), lin, 1, 1, (int)nT, 0, false, nullptr, 0, s));
@@ -489,6 +546,42 @@ int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int 
                       int* d_tokens, float* d_scores, ocrhip_stream stream) {
     OCR_HANDLE(h);
     return launch_ctc_greedy(d_logits, B, T, V, V, d_lengths, blank, d_tokens, d_scores, (hipStream_t)stream);
+}
+
+int ocrhip_profile_enable(ocrhip_handle h, int enable) {
+    OCR_HANDLE(h);
+    OCR_HIP_CHECK(hipDeviceSynchronize());
+    h->prof.recycle();
+    h->prof.enabled = enable != 0;
+    return OCRHIP_OK;
+}
+
+int ocrhip_profile_collect(ocrhip_handle h, ocrhip_kernel_stat* out, int cap, int* n) {
+    OCR_HANDLE(h);
+    OCR_REQUIRE(n && (out || cap == 0), "profile_collect: null argument");
+    OCR_HIP_CHECK(hipDeviceSynchronize());
+    std::map<std::string, ocrhip_kernel_stat> agg;
+    for (auto& r : h->prof.records) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        auto it = agg.find(r.name);
+        if (it == agg.end()) {
+            ocrhip_kernel_stat st;
+            std::memset(&st, 0, sizeof(st));
+            std::snprintf(st.name, sizeof(st.name), "%s", r.name.c_str());
+            it = agg.insert({r.name, st}).first;
+        }
+        it->second.launches += 1;
+        it->second.total_ms += ms;
+        it->second.flops += r.flops;
+        it->second.bytes += r.bytes;
+    }
+    std::vector<ocrhip_kernel_stat> v;
+    for (auto& kv : agg) v.push_back(kv.second);
+    std::sort(v.begin(), v.end(), [](const ocrhip_kernel_stat& a, const ocrhip_kernel_stat& b) { return a.total_ms > b.total_ms; });
+    *n = (int)v.size();
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+    return OCRHIP_OK;
 }
 
 }  // extern "C"

@@ -40,6 +40,31 @@ void set_error(const char* fmt, ...);
         if (_rc != OCRHIP_OK) return _rc; \
     } while (0)
 
+// Event-pair records of the stage timers (ocrhip_profile_*).
+struct ProfRecord {
+    std::string name;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+struct Profiler {
+    bool enabled = false;
+    std::vector<ProfRecord> records;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get_event();
+    void recycle();
+};
+Profiler* current_profiler();
+void set_current_profiler(Profiler* p);
+
+// RAII: records an event before and after the launches made in its scope (no-op when disabled).
+struct ProfScope {
+    Profiler* p;
+    hipStream_t s;
+    size_t idx;
+    ProfScope(const char* name, double flops, double bytes, hipStream_t stream);
+    ~ProfScope();
+};
+
 // Grow-only device buffer owned by a handle.
 struct DevBuf {
     void* ptr = nullptr;
@@ -101,6 +126,7 @@ struct ocrhip_ctx {
     ocrhip::CrnnNet crnn;
     ocrhip::DevBuf decode_stage;   // staging of the decode kernel
     ocrhip::DevBuf lanms_ws;       // scratch of the LANMS kernel
+    ocrhip::Profiler prof;
 };
 
 namespace ocrhip {

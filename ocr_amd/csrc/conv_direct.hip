@@ -154,6 +154,9 @@ int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y,
     OCR_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, "conv_first: bad sizes B=%d H=%d W=%d", B, H, W);
     const float* w = L.w_f32.as<float>();
     const float* bias = L.bias.as<float>();
+    const double px = (double)B * H * W;
+    ProfScope prof(L.cin == 3 ? "conv_first<3,64>" : "conv_first<1,32,pool>", 2.0 * 9 * L.cin * L.cout * px,
+                   px * L.cin * (x_is_u8 ? 1.0 : 4.0) + 4.0 * px * L.cout / (pool ? 4.0 : 1.0), s);
     if (L.cin == 3 && L.cout == 64 && pool == 0) {
         dim3 grid((W + 63) / 64, H, B), block(256);
         if (x_is_u8)
@@ -177,6 +180,7 @@ int launch_east_heads(const ConvLayer& L, const float* x, float* maps, int64_t n
     if (npix <= 0) return OCRHIP_OK;
     const int64_t blocks = (npix + 255) / 256;
     OCR_REQUIRE(blocks < (1ll << 31), "east_heads: too many pixels");
+    ProfScope prof("east_heads", 2.0 * 32 * 6 * (double)npix, 4.0 * (32 + 6) * (double)npix, s);
     hipLaunchKernelGGL(east_heads_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, L.w_f32.as<float>(),
                        L.bias.as<float>(), maps, npix);
     OCR_HIP_CHECK(hipGetLastError());

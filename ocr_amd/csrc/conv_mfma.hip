@@ -327,6 +327,21 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
         grid = dim3((unsigned)(a.tiles_x * tiles_y), L.cout_pad / BN, B);
     }
 
+    char pname[64];
+    std::snprintf(pname, sizeof(pname), "conv_mfma_f32<ks%d,n%d,pool%d,up%d>", ks, BN, pool, (int)(up_src != nullptr));
+    double out_px, in_elems;
+    if (ks == 1) {
+        out_px = (double)B * H * W;
+        in_elems = out_px * L.cin;
+    } else {
+        const int pad = (ks == 3) ? 1 : 0;
+        out_px = (double)B * (H - (ks - 1) + 2 * pad) * (W - (ks - 1) + 2 * pad);
+        in_elems = (double)B * H * W * L.cin;
+    }
+    const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : (pool == 2 ? 2.0 : 1.0));
+    ProfScope prof(pname, 2.0 * ks * ks * L.cin * L.cout * out_px,
+                   4.0 * (in_elems + out_elems + (double)ks * ks * L.cin * L.cout), s);
+
 #define OCR_CONV_CASE(KS_, NT_, POOL_, UP_)                                  \
     if (ks == KS_ && NT == NT_ && pool == POOL_ && (up_src != nullptr) == UP_) { \
         launch_variant<KS_, NT_, POOL_, UP_>(a, grid, s);                     \

@@ -145,6 +145,7 @@ int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* 
     OCR_REQUIRE(out_dtype == OCRHIP_F32 || out_dtype == OCRHIP_BF16, "crop_resize_pack: out_dtype must be F32 or BF16");
     if (n == 0) return OCRHIP_OK;
     dim3 grid(n, 4), block(256);
+    ProfScope prof("crop_resize_pack", 0.0, 0.0, s);
     if (out_dtype == OCRHIP_BF16)
         hipLaunchKernelGGL(crop_resize_pack_kernel<true>, grid, block, 0, s, img, B, H, W, rects, box_img, inter, out_w,
                            dst_off, out_h, packed);

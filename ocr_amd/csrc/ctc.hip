@@ -83,6 +83,7 @@ int launch_ctc_greedy(const float* logits, int B, int T, int V, int ld_v, const 
     OCR_REQUIRE(B >= 0 && T > 0 && V > 0 && ld_v >= V, "ctc_greedy: bad sizes B=%d T=%d V=%d ld=%d", B, T, V, ld_v);
     OCR_REQUIRE(T <= kMaxT, "ctc_greedy: T=%d exceeds the supported maximum %d", T, kMaxT);
     if (B == 0) return OCRHIP_OK;
+    ProfScope prof("ctc_greedy", 0.0, 4.0 * ((double)B * T * V + (double)B * T), s);
     hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), 0, s, logits, T, V, ld_v, lengths, blank, tokens, scores);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;

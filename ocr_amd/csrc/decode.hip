@@ -176,6 +176,8 @@ int launch_east_decode(ocrhip_ctx* h, const float* maps, int B, int mh, int mw, 
     auto* masks = h->decode_stage.as<unsigned long long>();
     int* chunk_counts = reinterpret_cast<int*>(reinterpret_cast<char*>(h->decode_stage.ptr) + mask_bytes);
     dim3 grid(nchunks, B), block(kChunk);
+    // algorithmic bytes: the 24 B/pixel map; the 36 B (+32 B polygon) per box depend on the data
+    ProfScope prof("east_decode", 0.0, 24.0 * (double)B * npix, s);
     hipLaunchKernelGGL(east_decode_flags, grid, block, 0, s, maps, mh, mw, in_h, in_w, thr, masks, chunk_counts);
     hipLaunchKernelGGL(east_decode_write, grid, block, 0, s, maps, mh, mw, in_h, in_w, masks, chunk_counts, cap, xyxy,
                        polys, scores, pix, counts);

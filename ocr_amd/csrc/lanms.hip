@@ -462,6 +462,7 @@ int launch_lanms(ocrhip_ctx* h, const float* xyxy, const float* scores, const in
     p.max_iter = max_iter; p.max_out = max_out;
     p.merged = merged; p.keep = keep; p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_src = out_src;
     p.out_counts = out_counts; p.n_iter = n_iter;
+    ProfScope prof("lanms", 0.0, 0.0, s);
     hipLaunchKernelGGL(lanms_kernel, dim3(B), dim3(kThreads), 0, s, p);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;

@@ -132,6 +132,7 @@ int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipSt
     const int64_t row_elems = (int64_t)W * C, total = (int64_t)B * row_elems;
     const int64_t blocks = (total / 4 + 255) / 256;
     OCR_REQUIRE(blocks < (1ll << 31), "mean_rows: too large");
+    ProfScope prof("mean_rows", (double)total * H, 4.0 * (double)total * (H + 1), s);
     hipLaunchKernelGGL(mean_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, H, row_elems, total);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;

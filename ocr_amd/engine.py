@@ -72,6 +72,18 @@ class HipContext:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ stage timers
+    def profile_enable(self, enable=True):
+        check(self.lib.ocrhip_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_collect(self, cap=64):
+        """-> list of dict(name, launches, total_ms, flops, bytes) sorted by total time (synchronises)."""
+        arr = (_lib.KernelStat * cap)()
+        n = ctypes.c_int(0)
+        check(self.lib.ocrhip_profile_collect(self._h, arr, cap, ctypes.byref(n)))
+        return [{'name': arr[i].name.decode(), 'launches': arr[i].launches, 'total_ms': arr[i].total_ms,
+                 'flops': arr[i].flops, 'bytes': arr[i].bytes} for i in range(min(cap, n.value))]
+
     # ------------------------------------------------------------------ EAST
     def east_load_weights(self, state_dict):
         arr, keep = _descs(state_dict)
