@@ -1,0 +1,166 @@
+"""`BaseOCR` / `CRNN` with the reference's interface (models/ocr/base_ocr.py:53-255,371-375,
+models/ocr/crnn.py:15-58), running on libocrhip.so.
+
+Differences a caller can observe, all by omission (NotImplementedError, never a silent change):
+`combine=True` (word -> line grouping) and `method='beam_search'` are not built yet, so the
+defaults here are `combine=False`, `method='greedy'`; callbacks / savers / streaming are out of scope.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from .. import register_model
+from ..detection.east import get_image_data, load_image
+from ...runtimes import HIPRuntime
+from ...utils.image_sizes import plan_crops
+from ...utils.text import CharTokenizer, ENGLISH_G2_CHARACTERS
+
+logger = logging.getLogger(__name__)
+
+
+class BaseOCR:
+    def __init__(self, lang='multi', weights=None, *, name='crnn_en', characters=ENGLISH_G2_CHARACTERS,
+                 input_size=(64, None, 1), image_normalization='easyocr', resize_kwargs=None, runtime='hip', device=0,
+                 max_output_length=None, **kwargs):
+        if runtime != 'hip':
+            raise ValueError('Unsupported runtime !\n  Accepted : {}\n  Got : {}'.format(('hip',), runtime))
+        self.lang = lang
+        self.name = name
+        self.input_size = tuple(input_size)
+        self.image_normalization = image_normalization
+        self.resize_kwargs = resize_kwargs or {'antialias': True, 'interpolation': 'bilinear',
+                                               'preserve_aspect_ratio': True, 'pad_mode': 'repeat_last',
+                                               'multiples': 64}
+        self.max_output_length = max_output_length
+        self.tokenizer = CharTokenizer(characters)
+        self.runtime = runtime
+        if isinstance(weights, dict):
+            self.model = HIPRuntime('state_dict:' + name, state_dict=weights, device=device, reload=True)
+        else:
+            self.model = HIPRuntime(weights if weights is not None
+                                    else 'random:crnn:{}:0'.format(self.tokenizer.vocab_size), device=device)
+        self.ctx = self.model.engine.ctx
+        if self.ctx.vocab_size != self.tokenizer.vocab_size:
+            raise ValueError('The checkpoint predicts {} classes but the vocabulary has {} symbols'.format(
+                self.ctx.vocab_size, self.tokenizer.vocab_size))
+        register_model(name, self)
+
+    is_encoder_decoder = False
+
+    @property
+    def vocab_size(self):
+        return self.tokenizer.vocab_size
+
+    @property
+    def blank_token_idx(self):
+        return self.tokenizer.blank_token_idx
+
+    @property
+    def compiled_infer(self):
+        return self.model
+
+    # ---- one row, as the reference prepares it (base_image_model.py:93-131 with use_box=True)
+    def get_input(self, data, **kwargs):
+        """{'filename': image, 'boxes': {'boxes': row, 'format': 'xyxy'}} -> (64, Wpad, 1) float32 GPU tensor
+        (a tensor with a zero dimension for an empty crop)."""
+        image = load_image(data)
+        boxes = data['boxes']['boxes'] if isinstance(data['boxes'], dict) else data['boxes']
+        out = self._pack(torch.from_numpy(np.ascontiguousarray(image)).to(self.ctx.device)[None],
+                         [np.asarray(boxes, dtype=np.float32).reshape(-1, 4)[:1]])
+        if out is None:
+            return torch.zeros((64, 0, 1), device=self.ctx.device)
+        packed, plan, off = out
+        return packed.view(64, int(plan['out_w'][0]), 1)
+
+    def _pack(self, d_images, boxes_per_image):
+        B, H, W, _ = d_images.shape
+        plans, box_img = [], []
+        for b, boxes in enumerate(boxes_per_image):
+            p = plan_crops(boxes, H, W)
+            plans.append(p)
+            box_img.append(np.full(len(p['index']), b, dtype=np.int32))
+        plan = {k: np.concatenate([p[k] for p in plans]) for k in ('rects', 'inter', 'out_w', 'index')}
+        plan['box_img'] = np.concatenate(box_img)
+        n = len(plan['out_w'])
+        if n == 0:
+            return None
+        off = np.concatenate([[0], np.cumsum(64 * plan['out_w'].astype(np.int64))])
+        dev = d_images.device
+        packed = self.ctx.crop_resize_pack(
+            d_images, torch.from_numpy(plan['rects']).to(dev), torch.from_numpy(plan['box_img']).to(dev),
+            torch.from_numpy(plan['inter']).to(dev), torch.from_numpy(plan['out_w']).to(dev),
+            torch.from_numpy(off[:-1].astype(np.int64)).to(dev), int(off[-1]))
+        return packed, plan, off
+
+    def recognise_rows(self, image, rows, method='greedy'):
+        """All rows of one image in one go -> (index of valid rows, texts, scores)."""
+        if method != 'greedy':
+            raise NotImplementedError('CTC {} decoding is not available in this build (greedy only)'.format(method))
+        if image.dtype != np.uint8:
+            image = np.clip(np.asarray(image) * 255, 0, 255).astype(np.uint8) if image.dtype.kind == 'f' else image.astype(np.uint8)
+        if image.shape[2] == 1:
+            image = np.repeat(image, 3, axis=2)
+        d_img = torch.from_numpy(np.ascontiguousarray(image)).to(self.ctx.device)[None]
+        out = self._pack(d_img, [np.asarray(rows, dtype=np.float32).reshape(-1, 4)])
+        if out is None:
+            return [], [], np.zeros((0,), np.float32)
+        packed, plan, off = out
+        texts, scores = [None] * len(plan['index']), np.zeros(len(plan['index']), np.float32)
+        for wpad in np.unique(plan['out_w']):
+            sel = np.nonzero(plan['out_w'] == wpad)[0]
+            crops = torch.stack([packed[off[j]:off[j + 1]].view(64, int(wpad)) for j in sel])
+            res = self.ctx.crnn_forward(crops.contiguous(), want_logits=False, want_tokens=True)
+            toks, sc = res['tokens'].cpu().numpy(), res['scores'].cpu().numpy()
+            for k, j in enumerate(sel):
+                texts[j] = self.tokenizer.decode(toks[k])
+                scores[j] = sc[k]
+        return list(plan['index']), texts, scores
+
+    def infer(self, data, *, detector='east', detector_kwargs={'merge_method': 'union'}, combine=False,
+              box_filters=None, dezoom_factor=1., method='greedy', num_beams=10, num_sentences=1, length_power=.25,
+              threshold=0., box_callback=None, callbacks=None, predicted=None, overwrite=False, return_output=True,
+              **kwargs):
+        """base_ocr.py:98-255.  Returns dict(filename, boxes, ocr=[dict(boxes, rows, text, format, scores)], image)."""
+        if predicted and not overwrite and isinstance(data, str) and data in predicted:
+            return predicted[data]
+        if combine:
+            raise NotImplementedError('combine=True (grouping words into lines) is not available in this build')
+        if box_filters or dezoom_factor != 1.:
+            raise NotImplementedError('box_filters / dezoom_factor are not available in this build')
+        filename, image = get_image_data(data)
+        if not isinstance(data, dict) or 'boxes' not in data:
+            if isinstance(detector, str):
+                from .. import get_pretrained
+                detector = get_pretrained(detector, **detector_kwargs)
+            data = detector.infer(image)
+        boxes = data['boxes']
+        if isinstance(boxes, dict):
+            boxes = boxes['boxes']
+        boxes = np.asarray(boxes, dtype=np.float32).reshape(-1, 4)
+        index, texts, scores = self.recognise_rows(np.asarray(image), boxes, method=method)
+        n_skipped = len(boxes) - len(index)
+        if n_skipped:
+            logger.warning('Invalid input encountered : %d empty crops skipped', n_skipped)
+        ocr_results = []
+        for k, i in enumerate(index):
+            sc = np.array([scores[k]], dtype=np.float32)
+            if threshold < 0. and np.any(sc < threshold):
+                continue
+            info = {'boxes': boxes[i], 'rows': boxes[i:i + 1], 'text': texts[k], 'format': 'xyxy', 'scores': sc}
+            ocr_results.append(info)
+            if box_callback is not None:
+                box_callback(info, image=image)
+        return {'filename': filename, 'boxes': data.get('boxes', None) if isinstance(data, dict) else None,
+                'ocr': ocr_results, 'image': image}
+
+    def predict(self, inputs, **kwargs):
+        """base_ocr.py:371-375: a single image / filename / dict, or a list of them -> list of results."""
+        if isinstance(inputs, (str, dict)) or (hasattr(inputs, 'shape') and len(inputs.shape) == 3):
+            inputs = [inputs]
+        return [self.infer(inp, **kwargs) for inp in inputs]
+
+
+class CRNN(BaseOCR):
+    """models/ocr/crnn.py: EasyOCR recogniser (64 x W x 1 input, 'easyocr' normalisation, char vocabulary
+    ['<blank>'] + characters)."""

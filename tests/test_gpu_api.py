@@ -1,0 +1,101 @@
+"""The reference-shaped Python API (EAST, BaseOCR, ocr(), HIPRuntime, nms dispatcher) on the GPU,
+checked against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def models():
+    from ocr_amd.models.detection import EAST
+    from ocr_amd.models.ocr import CRNN
+    from ocr_amd.weights import random_crnn_params, random_east_params
+    ep, cp = random_east_params(5), random_crnn_params(97, seed=6)
+    return EAST(ep, name='east'), CRNN(weights=cp, name='crnn_en'), ep, cp
+
+
+def test_east_infer_and_decode(models):
+    from ocr_amd import synth
+    from oracle import image as oimg, nets, pipeline as opipe
+    east, _, ep, _ = models
+    images, maps, _ = synth.make_pages(31, 1, 256, 384, 20)
+    res = east.infer(images[0])
+    assert set(res) >= {'filename', 'boxes', 'image', 'output'}
+    assert res['output'].shape == (64, 96, 6) and res['boxes']['format'] in ('xyxy', 'poly')
+    ref = nets.east_forward(ep, oimg.prepare_east_input(images[0])[None])[0].numpy()
+    np.testing.assert_allclose(res['output'], ref, rtol=1e-4, atol=1e-5)
+    # decode_output on given maps == reference-faithful CPU decode + LANMS
+    got = east.decode_output(maps[0], inputs=np.zeros((1, 256, 384, 3), np.float32))
+    _, boxes, _ = opipe.detect_page(images[0], None, maps_override=maps[0], run_network=False)
+    assert got['format'] == 'xyxy'
+    np.testing.assert_array_equal(got['boxes'], boxes)
+    polys = east.decode_output(maps[0], inputs=np.zeros((1, 256, 384, 3), np.float32), nms_threshold=1.)
+    assert polys['format'] == 'poly' and polys['boxes'].shape[1:] == (4, 2)
+
+
+def test_east_input_not_multiple_of_32(models):
+    from oracle import image as oimg, nets
+    east, _, ep, _ = models
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (250, 390, 3), dtype=np.uint8)
+    x = east.get_input(img)
+    assert tuple(x.shape) == (256, 416, 3)
+    ref_in = oimg.prepare_east_input(img)
+    np.testing.assert_allclose(x.cpu().numpy(), ref_in, rtol=0, atol=2e-5)
+    out = east.infer(img)['output']
+    ref = nets.east_forward(ep, ref_in[None])[0].numpy()
+    np.testing.assert_allclose(out, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_base_ocr_infer_and_ocr_function(models):
+    from ocr_amd import synth
+    from ocr_amd.models.ocr import ocr
+    from ocr_amd.utils.text import ENGLISH_G2_CHARACTERS
+    from oracle import ctc as octc, pipeline as opipe
+    east, crnn, ep, cp = models
+    images, maps, _ = synth.make_pages(32, 1, 256, 384, 20)
+    boxes = east.decode_output(maps[0], inputs=np.zeros((1, 256, 384, 3), np.float32))
+    res = crnn.infer({'image': images[0], 'boxes': boxes})
+    assert set(res) == {'filename', 'boxes', 'ocr', 'image'}
+    index, texts, scores = opipe.recognise_rows(images[0], boxes['boxes'], cp, octc.CharTokenizer(ENGLISH_G2_CHARACTERS))
+    assert len(res['ocr']) == len(index) >= 10
+    wrong = sum(1 for r, t in zip(res['ocr'], texts) if r['text'] != t)
+    assert wrong <= 1
+    for r, i, s in zip(res['ocr'], index, scores):
+        assert r['format'] == 'xyxy' and r['rows'].shape == (1, 4)
+        np.testing.assert_array_equal(r['boxes'], boxes['boxes'][i])
+        assert abs(float(r['scores'][0]) - float(s)) < 1e-3
+    # get_input for one row == the oracle's prepared crop
+    from oracle import boxes as obox, image as oimg
+    inp = crnn.get_input({'filename': images[0], 'boxes': {'boxes': boxes['boxes'][0:1], 'format': 'xyxy'}})
+    ref = oimg.prepare_crnn_input(obox.crop_box(images[0], boxes['boxes'][0])[1], resize='numpy')
+    np.testing.assert_array_equal(inp.cpu().numpy(), ref)
+    # the public function: detector by name, random-weight detection -> just the structure
+    out = ocr(images[0], model='crnn_en', detector='east')
+    assert isinstance(out, list) and len(out) == 1 and 'ocr' in out[0]
+    with pytest.raises(NotImplementedError):
+        crnn.infer(images[0], combine=True)
+    with pytest.raises(NotImplementedError):
+        crnn.infer({'image': images[0], 'boxes': boxes}, method='beam_search')
+
+
+def test_runtime_object_and_nms_dispatch(models):
+    from ocr_amd.runtimes import HIPRuntime, build_runtime
+    from ocr_amd.utils.boxes import nms
+    from oracle import nets
+    east, crnn, ep, cp = models
+    rt = build_runtime('hip', 'random:crnn:97:6')
+    assert isinstance(rt, HIPRuntime) and rt.path == 'random:crnn:97:6' and rt.layers == []
+    assert build_runtime('hip', 'random:crnn:97:6').engine is rt.engine          # class-level engine cache
+    x = np.random.default_rng(1).uniform(-1, 1, (1, 64, 128, 1)).astype(np.float32)
+    out = rt(x, method='beam_search', num_beams=10, num_sentences=1, length_power=.25)   # extra kwargs ignored
+    assert isinstance(out, np.ndarray) and out[0].shape == (31, 97) and len(out) == 1
+    ref = nets.crnn_forward(cp, x).numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()))
+    chain = np.array([[0, 0, 0.2, 0.2], [0.1, 0.1, 0.3, 0.3], [0.2, 0.2, 0.4, 0.4], [0.3, 0.3, 0.5, 0.5]], 'float32')
+    boxes, scores, valid = nms(chain, nms_threshold=0.1, merge_threshold=0.1, source='xyxy', method='lanms')
+    np.testing.assert_allclose(boxes[valid], [[0, 0, 0.3, 0.3], [0.2, 0.2, 0.5, 0.5]], atol=1e-6)
+    assert boxes.shape == (4, 4) and valid.dtype == bool

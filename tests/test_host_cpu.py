@@ -1,0 +1,90 @@
+"""CPU-only checks: the C ABI library loads and exports every symbol the header declares, and the
+host-side logic (size arithmetic, slice semantics, tokenizer, registries) follows the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ocr_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'ocrhip.h')).read()
+    declared = set(re.findall(r'\b(ocrhip_[a-z_0-9]+)\s*\(', header))
+    assert len(declared) >= 17
+    assert declared == set(_lib.SIGNATURES.keys())
+    lib = _lib.load()                      # raises if the .so is missing or a symbol is not exported
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.ocrhip_version() >= 100
+
+
+def test_size_arithmetic_matches_reference_golden(golden):
+    from ocr_amd.utils import image_sizes as S
+    from oracle import image as oimg
+    for h, w, out in zip(golden['crnn_size_h'], golden['crnn_size_w'], golden['crnn_size_out']):
+        assert S.crnn_output_size(int(h), int(w)) == (int(out[0]), int(out[1]))
+        (ih, iw), (oh, ow) = oimg.crnn_sizes(int(h), int(w))
+        assert S.crnn_intermediate_size(int(h), int(w), oh, ow) == (ih, iw)
+    for (h, w), out in zip(golden['east_size_in'], golden['east_size_out']):
+        assert S.east_input_size(int(h), int(w)) == (int(out[0]), int(out[1]))
+
+
+def test_crop_rectangles_match_reference_golden(golden):
+    from ocr_amd.utils import image_sizes as S
+    H, W = int(golden['crop_image_shape'][0]), int(golden['crop_image_shape'][1])
+    rel = golden['crop_rel']
+    np.testing.assert_array_equal(S.relative_to_absolute(rel, H, W), golden['crop_abs'])
+    rects, valid = S.resolve_slices(golden['crop_abs'], H, W)
+    for r, v, shp in zip(rects, valid, golden['crop_shapes']):
+        assert (int(r[3] - r[1]), int(r[2] - r[0])) == (int(shp[0]), int(shp[1]))
+        assert bool(v) == (shp[0] > 0 and shp[1] > 0)
+
+
+def test_uint8_to_float_is_one_rounding():
+    # x / 255 in float64 then float32 (reference) == float32 division (kernels) for every byte value
+    u = np.arange(256)
+    np.testing.assert_array_equal((u / 255).astype(np.float32), u.astype(np.float32) / np.float32(255))
+
+
+def test_tokenizer_follows_reference_rules():
+    from ocr_amd.utils.text import CharTokenizer, ENGLISH_G2_CHARACTERS
+    from oracle.ctc import CharTokenizer as OracleTok
+    tok = CharTokenizer()
+    assert tok.vocab_size == 97 and tok.blank_token_idx == 0
+    dup = CharTokenizer('abca')            # setdefault: the second 'a' keeps id 1, vocabulary shrinks
+    assert dup.vocab_size == 4
+    rng = np.random.default_rng(0)
+    o = OracleTok(ENGLISH_G2_CHARACTERS)
+    for _ in range(50):
+        row = rng.integers(-1, 97, 30)
+        assert tok.decode(row) == o.decode(row)
+    assert tok.decode([5, 0, 0, 7]) == tok._id_to_symbol[5]          # two blanks in a row end the text
+    assert tok.decode([-1, -1]) == ''
+
+
+def test_registries_raise_like_the_reference():
+    from ocr_amd.models import get_pretrained
+    from ocr_amd.runtimes import build_runtime
+    from ocr_amd.utils.boxes import nms, convert_box_format
+    with pytest.raises(ValueError, match='does not exist'):
+        get_pretrained('no_such_model')
+    with pytest.raises(ValueError, match='Unsupported runtime'):
+        build_runtime('trt', 'x')
+    with pytest.raises(ValueError, match='Unknown NMS method'):
+        nms(np.zeros((2, 4), np.float32), nms_threshold=0.2, method='nope')
+    b, s, m = nms(np.zeros((0, 4), np.float32), nms_threshold=0.2)
+    assert len(m) == 0
+    b, s, m = nms(np.ones((3, 4), np.float32), nms_threshold=1.0)
+    assert m.all()
+    called = {}
+
+    def custom(boxes, scores, max_output_size, nms_threshold, **kw):
+        called['ok'] = True
+        return boxes, scores, np.ones(len(boxes), bool)
+    nms(np.ones((3, 4), np.float32), nms_threshold=0.2, method=custom)
+    assert called['ok']
+    polys = np.array([[[0.1, 0.2], [0.5, 0.2], [0.5, 0.4], [0.1, 0.4]]], np.float32)
+    np.testing.assert_allclose(convert_box_format(polys, source='poly', target='xyxy'), [[0.1, 0.2, 0.5, 0.4]], atol=1e-7)
