@@ -99,23 +99,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
 
     const float* wslab = a.w + (int64_t)nb * nK * B_FLOATS;
 
-    for (int kc = 0; kc < nK; ++kc) {
-        const int c0 = kc * CK;
-        __syncthreads();   // the previous chunk has been consumed
+    // Software pipeline over the K chunks: the global loads of chunk k+1 are issued into registers
+    // before the matrix work of chunk k and written to LDS after it, so their latency hides behind
+    // 144 MFMAs per wave.
+    constexpr int V4 = CK / 4;
+    constexpr int A_V4 = NPIX * V4, B_V4 = B_FLOATS / 4;
+    constexpr int A_IT = (A_V4 + 255) / 256, B_IT = (B_V4 + 255) / 256;
+    float4 ra[A_IT], rb[B_IT];
 
-        // ---- stage the weight slab (contiguous copy)
-        {
-            const float4* src = reinterpret_cast<const float4*>(wslab + (int64_t)kc * B_FLOATS);
-            float4* dst = reinterpret_cast<float4*>(Bs);
-#pragma unroll 4
-            for (int f = tid; f < B_FLOATS / 4; f += 256) dst[f] = src[f];
+    auto load_chunk = [&](int kc) {
+        const int c0 = kc * CK;
+        const float4* src = reinterpret_cast<const float4*>(wslab + (int64_t)kc * B_FLOATS);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int f = tid + i * 256;
+            rb[i] = (B_V4 % 256 == 0 || f < B_V4) ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        // ---- stage the input tile
-        constexpr int V4 = CK / 4;
         if (KS == 1) {
             const bool from_up = UPCAT && (c0 < a.up_c);
-#pragma unroll 2
-            for (int f = tid; f < NPIX * V4; f += 256) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int f = tid + i * 256;
                 const int px = f / V4, c4 = f % V4;
                 const int64_t m = m0 + px;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -144,20 +148,41 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
                         v.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
                     }
                 }
-                *reinterpret_cast<float4*>(&As[px * PS + c4 * 4]) = v;
+                ra[i] = v;
             }
         } else {
-#pragma unroll 2
-            for (int f = tid; f < NPIX * V4; f += 256) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int f = tid + i * 256;
                 const int px = f / V4, c4 = f % V4;
                 const int gy = y0 - PAD + px / WT, gx = x0 - PAD + px % WT;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                if ((A_V4 % 256 == 0 || f < A_V4) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                     v = *reinterpret_cast<const float4*>(a.x + (((int64_t)b * a.H + gy) * a.W + gx) * a.cin + c0 + c4 * 4);
-                *reinterpret_cast<float4*>(&As[px * PS + c4 * 4]) = v;
+                ra[i] = v;
             }
         }
-        __syncthreads();
+    };
+
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int f = tid + i * 256;
+            if (B_V4 % 256 == 0 || f < B_V4) reinterpret_cast<float4*>(Bs)[f] = rb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int f = tid + i * 256;
+            if (A_V4 % 256 == 0 || f < A_V4) *reinterpret_cast<float4*>(&As[(f / V4) * PS + (f % V4) * 4]) = ra[i];
+        }
+    };
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+
+    for (int kc = 0; kc < nK; ++kc) {
+        if (kc + 1 < nK) load_chunk(kc + 1);
 
         // ---- matrix work of this chunk
 #pragma unroll
@@ -190,6 +215,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
                         for (int nt = 0; nt < NT; ++nt)
                             acc[r][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r][t], bv[nt][t], acc[r][nt], 0, 0, 0);
             }
+        }
+
+        if (kc + 1 < nK) {
+            __syncthreads();   // every wave has finished reading this chunk from LDS
+            store_chunk();
+            __syncthreads();
         }
     }
 
