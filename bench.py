@@ -89,9 +89,13 @@ def main():
     d_img = torch.from_numpy(images).cuda()
     d_maps = torch.from_numpy(maps).cuda()
 
-    def step():
-        out = pipe(d_img, maps_override=d_maps)
-        return sum(int(o['valid'].sum()) for o in out), sum(len(o['boxes']) for o in out)
+    def run(n_steps):
+        # n_steps batches streamed through the pipeline (detection of batch i+1 is enqueued while the host
+        # prepares the crops of batch i); every batch is completed, strings included, before run() returns
+        w = bx = 0
+        for out in pipe.run_batches((d_img, d_maps) for _ in range(n_steps)):
+            w, bx = sum(int(o['valid'].sum()) for o in out), sum(len(o['boxes']) for o in out)
+        return w, bx
 
     def sync():
         torch.cuda.synchronize()
@@ -99,13 +103,12 @@ def main():
             dist.barrier()
 
     words = boxes = 0
-    for _ in range(args.warmup):
-        words, boxes = step()
+    if args.warmup:
+        words, boxes = run(args.warmup)
     pipe.ctx.profile_enable(True)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        words, boxes = step()
+    words, boxes = run(args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     stats = pipe.ctx.profile_collect()

@@ -164,6 +164,22 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
                         float* d_logits, int* d_tokens, float* d_scores, ocrhip_stream stream);
 int ocrhip_crnn_vocab_size(ocrhip_handle h);
 
+/* CRNN forward + CTC greedy for a whole batch of crops of DIFFERENT widths in one call: what
+ * BaseOCR.infer does for all the rows of an image (one forward per row, pad_batch of the logits,
+ * ctc_decode with lengths; models/ocr/base_ocr.py:171-222, utils/sequence_utils.py:16-62).  The
+ * feature extractor runs once per group of equal width; the recurrent layers, the Dense layers and
+ * the CTC decoding run once over all sequences (ragged: sequence i has T_i = out_w[i]/4 - 1 steps).
+ *   d_packed : device, crop i is a (64, out_w[i]) float32 plane; planes back to back in crop order
+ *              (the layout ocrhip_crop_resize_pack writes for cumulative dst offsets)
+ *   out_w    : HOST (n) int32 padded widths, non-decreasing
+ *   t_stride : row stride of d_tokens, >= max_i T_i
+ *   d_logits : device (sum_i T_i, V) float32, sequences back to back, or NULL
+ *   d_tokens : device (n, t_stride) int32 padded with -1, or NULL;  d_scores: device (n) float32
+ *   d_lengths: device (n) int32 receives T_i, or NULL */
+int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int* out_w, int n, int compute_dtype,
+                               int t_stride, float* d_logits, int* d_tokens, float* d_scores, int* d_lengths,
+                               ocrhip_stream stream);
+
 /* Debug / test access to an activation of the last ocrhip_crnn_forward call (synchronises).
  *   name: "features" (n,T,256), "seq0", "seq1" (n,T,256) */
 int ocrhip_crnn_get_activation(ocrhip_handle h, const char* name, float* dst, int64_t dst_capacity,

@@ -79,6 +79,32 @@ int DevBuf::reserve(size_t need) {
     return OCRHIP_OK;
 }
 
+int PinnedRing::upload(void* dst, const void* src, size_t n, hipStream_t s) {
+    const int k = next;
+    next = (next + 1) % kSlots;
+    if (done[k]) OCR_HIP_CHECK(hipEventSynchronize(done[k]));          // the copy that last used this slot has finished
+    else OCR_HIP_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+    if (bytes[k] < n) {
+        if (host[k]) OCR_HIP_CHECK(hipHostFree(host[k]));
+        host[k] = nullptr;
+        bytes[k] = 0;
+        OCR_HIP_CHECK(hipHostMalloc(&host[k], n, hipHostMallocDefault));
+        bytes[k] = n;
+    }
+    std::memcpy(host[k], src, n);
+    OCR_HIP_CHECK(hipMemcpyAsync(dst, host[k], n, hipMemcpyHostToDevice, s));
+    OCR_HIP_CHECK(hipEventRecord(done[k], s));
+    return OCRHIP_OK;
+}
+
+void PinnedRing::release() {
+    for (int k = 0; k < kSlots; ++k) {
+        if (host[k]) (void)hipHostFree(host[k]);
+        if (done[k]) (void)hipEventDestroy(done[k]);
+        host[k] = nullptr; done[k] = nullptr; bytes[k] = 0;
+    }
+}
+
 void DevBuf::release() {
     if (ptr) (void)hipFree(ptr);
     ptr = nullptr;
@@ -241,8 +267,9 @@ int ocrhip_destroy(ocrhip_handle h) {
     }
     free_layer(h->crnn.pred);
     for (auto& b : h->crnn.act) b.release();
-    for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits})
+    for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits, &h->crnn.meta})
         b->release();
+    h->crnn.ring.release();
     h->decode_stage.release();
     h->lanms_ws.release();
     h->prof.recycle();
@@ -460,6 +487,69 @@ int ocrhip_crnn_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n
 
 int ocrhip_crnn_vocab_size(ocrhip_handle h) { return (h && h->crnn.loaded) ? h->crnn.vocab : 0; }
 
+// Feature extractor for a batch of equal-width crops: (n,64,Wpad,1) -> feats (n,T,256), T = Wpad/4 - 1.
+static int crnn_features(CrnnNet& net, const float* x, int n, int Wpad, float* feats, hipStream_t s) {
+    const int Hin = 64, Hd = net.hidden;
+    const int T = Wpad / 4 - 1;
+    const size_t nW = (size_t)n * Wpad;
+    OCR_TRY(net.act[0].reserve(nW * 512 * sizeof(float)));      // (n,32,W/2,32) is the largest
+    OCR_TRY(net.act[1].reserve(nW * 256 * sizeof(float)));      // (n,16,W/4,64)
+    float* A = net.act[0].as<float>();
+    float* Bf = net.act[1].as<float>();
+    OCR_TRY(launch_conv_first(net.conv[0], x, false, A, n, Hin, Wpad, 1, s));                       // (n,32,W/2,32)
+    OCR_TRY(launch_conv_mfma(net.conv[1], A, Bf, n, 32, Wpad / 2, 1, true, nullptr, 0, s));         // (n,16,W/4,64)
+    OCR_TRY(launch_conv_mfma(net.conv[2], Bf, A, n, 16, Wpad / 4, 0, true, nullptr, 0, s));         // (n,16,W/4,128)
+    OCR_TRY(launch_conv_mfma(net.conv[3], A, Bf, n, 16, Wpad / 4, 2, true, nullptr, 0, s));         // (n,8,W/4,128)
+    OCR_TRY(launch_conv_mfma(net.conv[4], Bf, A, n, 8, Wpad / 4, 0, true, nullptr, 0, s));          // (n,8,W/4,256)
+    OCR_TRY(launch_conv_mfma(net.conv[5], A, Bf, n, 8, Wpad / 4, 2, true, nullptr, 0, s));          // (n,4,W/4,256)
+    OCR_TRY(launch_conv_mfma(net.conv[6], Bf, A, n, 4, Wpad / 4, 0, true, nullptr, 0, s));          // (n,3,T,256)
+    OCR_TRY(launch_mean_rows(A, feats, n, 3, T, Hd, s));
+    return OCRHIP_OK;
+}
+
+// 2 x [BiLSTM(256) -> Dense(256)] -> Dense(vocab) over R = sum of T rows of `feats`.
+// Uniform mode: seq_T == nullptr, every sequence has Tmax steps.  Ragged mode: host_T (non-decreasing)
+// and the device arrays d_T / d_row0 describe the sequences.
+static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int Tmax, const int* host_T,
+                         const int* d_T, const int* d_row0, float* logits, hipStream_t s) {
+    const int Hd = net.hidden;
+    OCR_REQUIRE(R < (1ll << 31), "crnn: too many time steps in one batch");
+    OCR_TRY(net.xw.reserve((size_t)2 * R * 4 * Hd * sizeof(float)));
+    OCR_TRY(net.hbuf.reserve((size_t)2 * 2 * n * Hd * sizeof(float)));
+    OCR_TRY(net.cbuf.reserve((size_t)2 * n * Hd * sizeof(float)));
+    OCR_TRY(net.seq.reserve((size_t)R * 2 * Hd * sizeof(float)));
+    OCR_TRY(net.lin.reserve((size_t)2 * R * Hd * sizeof(float)));
+    const float* layer_in = feats;
+    for (int l = 0; l < 2; ++l) {
+        float* xw_f = net.xw.as<float>();
+        float* xw_b = xw_f + (size_t)R * 4 * Hd;
+        OCR_TRY(launch_conv_mfma(net.wih[l][0], layer_in, xw_f, 1, 1, (int)R, 0, false, nullptr, 0, s));
+        OCR_TRY(launch_conv_mfma(net.wih[l][1], layer_in, xw_b, 1, 1, (int)R, 0, false, nullptr, 0, s));
+        float* hb0 = net.hbuf.as<float>();
+        float* hb1 = hb0 + (size_t)2 * n * Hd;
+        {
+            // one timer scope for the whole recurrence of a layer (Tmax launches, both directions each)
+            ProfScope prof("lstm_layer(T steps)", 2.0 * 2 * 4.0 * Hd * Hd * (double)(R - n),
+                           4.0 * (2.0 * R * 4 * Hd + (double)R * 2 * Hd) + 4.0 * 2 * 4 * Hd * Hd * Tmax, s);
+            int first = 0;
+            for (int step = 0; step < Tmax; ++step) {
+                if (host_T)
+                    while (first < n && host_T[first] <= step) ++first;     // sequences shorter than step+1 are done
+                const float* hp = (step & 1) ? hb1 : hb0;
+                float* hn = (step & 1) ? hb0 : hb1;
+                OCR_TRY(launch_lstm_step(xw_f, xw_b, net.whh[l][0].as<float>(), net.whh[l][1].as<float>(), hp, hn,
+                                         net.cbuf.as<float>(), net.seq.as<float>(), n, Tmax, step, d_T, d_row0, first, s));
+            }
+        }
+        float* lin = net.lin.as<float>() + (size_t)l * R * Hd;
+        OCR_TRY(launch_conv_mfma(net.linear[l], net.seq.as<float>(), lin, 1, 1, (int)R, 0, false, nullptr, 0, s));
+        record(net.taps, l == 0 ? "seq0" : "seq1", lin, 1, R, Hd, 1);
+        layer_in = lin;
+    }
+    OCR_TRY(launch_conv_mfma(net.pred, layer_in, logits, 1, 1, (int)R, 0, false, nullptr, 0, s));
+    return OCRHIP_OK;
+}
+
 int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, int compute_dtype, float* d_logits,
                         int* d_tokens, float* d_scores, ocrhip_stream stream) {
     OCR_HANDLE(h);
@@ -473,67 +563,86 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
     OCR_REQUIRE(d_logits || d_tokens, "crnn_forward: ask for logits and/or tokens");
     OCR_REQUIRE(!d_tokens || d_scores, "crnn_forward: d_scores is required with d_tokens");
     hipStream_t s = (hipStream_t)stream;
-    const int Hin = 64, Hd = net.hidden;
+    const int Hd = net.hidden;
     const int T = Wpad / 4 - 1;
     OCR_REQUIRE(T >= 1, "crnn_forward: crop too narrow");
-    const size_t nW = (size_t)n * Wpad;
-    OCR_TRY(net.act[0].reserve(nW * 512 * sizeof(float)));      // (n,32,W/2,32) is the largest
-    OCR_TRY(net.act[1].reserve(nW * 256 * sizeof(float)));      // (n,16,W/4,64)
-    float* A = net.act[0].as<float>();
-    float* Bf = net.act[1].as<float>();
-    const float* x = reinterpret_cast<const float*>(d_crops);
-
-    OCR_TRY(launch_conv_first(net.conv[0], x, false, A, n, Hin, Wpad, 1, s));                       // (n,32,W/2,32)
-    OCR_TRY(launch_conv_mfma(net.conv[1], A, Bf, n, 32, Wpad / 2, 1, true, nullptr, 0, s));         // (n,16,W/4,64)
-    OCR_TRY(launch_conv_mfma(net.conv[2], Bf, A, n, 16, Wpad / 4, 0, true, nullptr, 0, s));         // (n,16,W/4,128)
-    OCR_TRY(launch_conv_mfma(net.conv[3], A, Bf, n, 16, Wpad / 4, 2, true, nullptr, 0, s));         // (n,8,W/4,128)
-    OCR_TRY(launch_conv_mfma(net.conv[4], Bf, A, n, 8, Wpad / 4, 0, true, nullptr, 0, s));          // (n,8,W/4,256)
-    OCR_TRY(launch_conv_mfma(net.conv[5], A, Bf, n, 8, Wpad / 4, 2, true, nullptr, 0, s));          // (n,4,W/4,256)
-    OCR_TRY(launch_conv_mfma(net.conv[6], Bf, A, n, 4, Wpad / 4, 0, true, nullptr, 0, s));          // (n,3,T,256)
-
-    const size_t nT = (size_t)n * T;
-    OCR_TRY(net.feats.reserve(nT * Hd * sizeof(float)));
-    OCR_TRY(net.xw.reserve(2 * nT * 4 * Hd * sizeof(float)));
-    OCR_TRY(net.hbuf.reserve((size_t)2 * 2 * n * Hd * sizeof(float)));
-    OCR_TRY(net.cbuf.reserve((size_t)2 * n * Hd * sizeof(float)));
-    OCR_TRY(net.seq.reserve(nT * 2 * Hd * sizeof(float)));
-    OCR_TRY(net.lin.reserve(2 * nT * Hd * sizeof(float)));
+    const int64_t R = (int64_t)n * T;
+    OCR_TRY(net.feats.reserve((size_t)R * Hd * sizeof(float)));
     float* feats = net.feats.as<float>();
-    OCR_TRY(launch_mean_rows(A, feats, n, 3, T, Hd, s));
     net.taps.clear();
+    OCR_TRY(crnn_features(net, reinterpret_cast<const float*>(d_crops), n, Wpad, feats, s));
     record(net.taps, "features", feats, n, T, Hd, 1);
-
-    const float* layer_in = feats;
-    for (int l = 0; l < 2; ++l) {
-        float* xw_f = net.xw.as<float>();
-        float* xw_b = xw_f + nT * 4 * Hd;
-        OCR_TRY(launch_conv_mfma(net.wih[l][0], layer_in, xw_f, 1, 1, (int)nT, 0, false, nullptr, 0, s));
-        OCR_TRY(launch_conv_mfma(net.wih[l][1], layer_in, xw_b, 1, 1, (int)nT, 0, false, nullptr, 0, s));
-        float* hb0 = net.hbuf.as<float>();
-        float* hb1 = hb0 + (size_t)2 * n * Hd;
-        {
-        // one timer scope for the whole recurrence of a layer (T launches, both directions each)
-        ProfScope prof("lstm_layer(T steps)", 2.0 * 2 * (double)n * 4.0 * Hd * Hd * (T - 1),
-                       4.0 * (2.0 * nT * 4 * Hd + nT * 2 * Hd) + 4.0 * 2 * 4 * Hd * Hd * T, s);
-        for (int step = 0; step < T; ++step) {
-            const float* hp = (step & 1) ? hb1 : hb0;
-            float* hn = (step & 1) ? hb0 : hb1;
-            OCR_TRY(launch_lstm_step(xw_f, xw_b, net.whh[l][0].as<float>(), net.whh[l][1].as<float>(), hp, hn,
-                                     net.cbuf.as<float>(), net.seq.as<float>(), n, T, step, s));
-        }
-        }
-        float* lin = net.lin.as<float>() + (size_t)l * nT * Hd;
-        OCR_TRY(launch_conv_mfma(net.linear[l], net.seq.as<float>(), lin, 1, 1, (int)nT, 0, false, nullptr, 0, s));
-        record(net.taps, l == 0 ? "seq0" : "seq1", lin, n, T, Hd, 1);
-        layer_in = lin;
-    }
     float* logits = d_logits;
     if (!logits) {
-        OCR_TRY(net.logits.reserve(nT * net.vocab * sizeof(float)));
+        OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));
         logits = net.logits.as<float>();
     }
-    OCR_TRY(launch_conv_mfma(net.pred, layer_in, logits, 1, 1, (int)nT, 0, false, nullptr, 0, s));
-    if (d_tokens) OCR_TRY(launch_ctc_greedy(logits, n, T, net.vocab, net.vocab, nullptr, 0, d_tokens, d_scores, s));
+    OCR_TRY(crnn_sequence(net, feats, n, R, T, nullptr, nullptr, nullptr, logits, s));
+    if (d_tokens) OCR_TRY(launch_ctc_greedy(logits, n, T, net.vocab, net.vocab, nullptr, nullptr, 0, d_tokens, d_scores, s));
+    return OCRHIP_OK;
+}
+
+int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int* out_w, int n, int compute_dtype,
+                               int t_stride, float* d_logits, int* d_tokens, float* d_scores, int* d_lengths,
+                               ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    CrnnNet& net = h->crnn;
+    if (!net.loaded) {
+        set_error("crnn_forward_packed: weights not loaded");
+        return OCRHIP_ESTATE;
+    }
+    OCR_REQUIRE(d_packed && out_w && n > 0, "crnn_forward_packed: bad arguments n=%d", n);
+    OCR_REQUIRE(compute_dtype == OCRHIP_F32, "crnn_forward_packed: compute dtype %d not available in this build", compute_dtype);
+    OCR_REQUIRE(d_logits || d_tokens, "crnn_forward_packed: ask for logits and/or tokens");
+    OCR_REQUIRE(!d_tokens || d_scores, "crnn_forward_packed: d_scores is required with d_tokens");
+    hipStream_t s = (hipStream_t)stream;
+    const int Hd = net.hidden;
+    std::vector<int> meta((size_t)2 * n);        // [T of each crop | first row of each crop]
+    int64_t R = 0;
+    for (int i = 0; i < n; ++i) {
+        OCR_REQUIRE(out_w[i] >= 8 && out_w[i] % 4 == 0 && (i == 0 || out_w[i] >= out_w[i - 1]),
+                    "crnn_forward_packed: widths must be multiples of 4, >= 8 and non-decreasing (crop %d: %d)", i, out_w[i]);
+        meta[i] = out_w[i] / 4 - 1;
+        meta[n + i] = (int)R;
+        R += meta[i];
+        OCR_REQUIRE(R < (1ll << 31), "crnn_forward_packed: too many time steps in one batch");
+    }
+    const int Tmax = meta[n - 1];
+    OCR_REQUIRE(!d_tokens || t_stride >= Tmax, "crnn_forward_packed: t_stride %d is smaller than the longest sequence %d", t_stride, Tmax);
+    OCR_TRY(net.meta.reserve(meta.size() * sizeof(int)));
+    OCR_TRY(net.ring.upload(net.meta.ptr, meta.data(), meta.size() * sizeof(int), s));
+    const int* d_T = net.meta.as<int>();
+    const int* d_row0 = d_T + n;
+    if (d_lengths) OCR_HIP_CHECK(hipMemcpyAsync(d_lengths, d_T, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, s));
+
+    OCR_TRY(net.feats.reserve((size_t)R * Hd * sizeof(float)));
+    float* feats = net.feats.as<float>();
+    net.taps.clear();
+    // feature extractor: one pass per group of equal width, split so that a pass stays within the workspace budget
+    const int64_t max_elems = 1ll << 20;         // n_group * Wpad per pass (act[0] = 2 GB at most)
+    const float* x = reinterpret_cast<const float*>(d_packed);
+    int64_t off = 0;
+    for (int i = 0; i < n;) {
+        const int w = out_w[i];
+        int j = i;
+        while (j < n && out_w[j] == w) ++j;
+        const int per_pass = (int)std::max<int64_t>(1, max_elems / w);
+        for (int c0 = i; c0 < j; c0 += per_pass) {
+            const int c1 = std::min(j, c0 + per_pass);
+            OCR_TRY(crnn_features(net, x + off, c1 - c0, w, feats + (size_t)meta[n + c0] * Hd, s));
+            off += (int64_t)(c1 - c0) * 64 * w;
+        }
+        i = j;
+    }
+    record(net.taps, "features", feats, 1, R, Hd, 1);
+    float* logits = d_logits;
+    if (!logits) {
+        OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));
+        logits = net.logits.as<float>();
+    }
+    OCR_TRY(crnn_sequence(net, feats, n, R, Tmax, meta.data(), d_T, d_row0, logits, s));
+    if (d_tokens)
+        OCR_TRY(launch_ctc_greedy(logits, n, t_stride, net.vocab, net.vocab, d_T, d_row0, 0, d_tokens, d_scores, s));
     return OCRHIP_OK;
 }
 
@@ -545,7 +654,7 @@ int ocrhip_crnn_get_activation(ocrhip_handle h, const char* name, float* dst, in
 int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int V, const int* d_lengths, int blank,
                       int* d_tokens, float* d_scores, ocrhip_stream stream) {
     OCR_HANDLE(h);
-    return launch_ctc_greedy(d_logits, B, T, V, V, d_lengths, blank, d_tokens, d_scores, (hipStream_t)stream);
+    return launch_ctc_greedy(d_logits, B, T, V, V, d_lengths, nullptr, blank, d_tokens, d_scores, (hipStream_t)stream);
 }
 
 int ocrhip_profile_enable(ocrhip_handle h, int enable) {

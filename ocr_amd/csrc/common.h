@@ -75,6 +75,18 @@ struct DevBuf {
     T* as() const { return reinterpret_cast<T*>(ptr); }
 };
 
+// Small host->device parameter uploads without blocking the host: a ring of pinned slots, each
+// guarded by an event recorded after the copy that last used it.
+struct PinnedRing {
+    static constexpr int kSlots = 4;
+    void* host[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t bytes[kSlots] = {0, 0, 0, 0};
+    hipEvent_t done[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    int next = 0;
+    int upload(void* dst, const void* src, size_t n, hipStream_t s);
+    void release();
+};
+
 // One convolution / GEMM layer after batch-norm folding, in the device layouts the kernels read.
 struct ConvLayer {
     int cin = 0, cout = 0, ks = 0;
@@ -114,7 +126,8 @@ struct CrnnNet {
     ConvLayer linear[2];     // 512 -> 256
     ConvLayer pred;          // 256 -> vocab
     DevBuf act[2];
-    DevBuf feats, xw, hbuf, cbuf, seq, lin, logits;
+    DevBuf feats, xw, hbuf, cbuf, seq, lin, logits, meta;
+    PinnedRing ring;
     std::map<std::string, Activation> taps;
 };
 
@@ -166,10 +179,13 @@ int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* 
 // rnn.hip
 int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
 int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, const float* h_prev,
-                     float* h_next, float* c_state, float* out, int n, int T, int step, hipStream_t s);
+                     float* h_next, float* c_state, float* out, int n, int T, int step, const int* seq_T,
+                     const int* seq_row0, int first, hipStream_t s);
 
 // ctc.hip
-int launch_ctc_greedy(const float* logits, int B, int T, int V, int ld_v, const int* lengths, int blank,
+// row0 != nullptr: sequence b starts at row row0[b] of a flat (sum T, ld_v) logits matrix; T is then the
+// stride of the token rows.
+int launch_ctc_greedy(const float* logits, int B, int T, int V, int ld_v, const int* lengths, const int* row0, int blank,
                       int* tokens, float* scores, hipStream_t s);
 
 }  // namespace ocrhip

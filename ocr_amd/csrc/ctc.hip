@@ -13,7 +13,8 @@ namespace {
 constexpr int kMaxT = 2048;
 
 __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ logits, int T, int V, int ld_v,
-                                                         const int* __restrict__ lengths, int blank,
+                                                         const int* __restrict__ lengths,
+                                                         const int* __restrict__ row0, int blank,
                                                          int* __restrict__ tokens, float* __restrict__ scores) {
     __shared__ int s_idx[kMaxT];
     __shared__ float s_max[kMaxT];
@@ -24,10 +25,10 @@ __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int L = lengths ? lengths[b] : T;
     L = min(max(L, 0), T);
-    const float* row0 = logits + (int64_t)b * T * ld_v;
+    const float* first_row = logits + (row0 ? (int64_t)row0[b] : (int64_t)b * T) * ld_v;
 
     for (int t = wave; t < L; t += 4) {
-        const float* row = row0 + (int64_t)t * ld_v;
+        const float* row = first_row + (int64_t)t * ld_v;
         float best = -INFINITY;
         int best_i = 0x7fffffff;
         for (int v = lane; v < V; v += 64) {
@@ -77,14 +78,15 @@ __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict
 
 }  // namespace
 
-int launch_ctc_greedy(const float* logits, int B, int T, int V, int ld_v, const int* lengths, int blank, int* tokens,
-                      float* scores, hipStream_t s) {
+int launch_ctc_greedy(const float* logits, int B, int T, int V, int ld_v, const int* lengths, const int* row0, int blank,
+                      int* tokens, float* scores, hipStream_t s) {
+    OCR_REQUIRE(row0 == nullptr || lengths != nullptr, "ctc_greedy: row offsets need lengths");
     OCR_REQUIRE(logits && tokens, "ctc_greedy: logits and tokens are required");
     OCR_REQUIRE(B >= 0 && T > 0 && V > 0 && ld_v >= V, "ctc_greedy: bad sizes B=%d T=%d V=%d ld=%d", B, T, V, ld_v);
     OCR_REQUIRE(T <= kMaxT, "ctc_greedy: T=%d exceeds the supported maximum %d", T, kMaxT);
     if (B == 0) return OCRHIP_OK;
     ProfScope prof("ctc_greedy", 0.0, 4.0 * ((double)B * T * V + (double)B * T), s);
-    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), 0, s, logits, T, V, ld_v, lengths, blank, tokens, scores);
+    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), 0, s, logits, T, V, ld_v, lengths, row0, blank, tokens, scores);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }

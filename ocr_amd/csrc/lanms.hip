@@ -33,6 +33,7 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
+constexpr int kCells = 64;                 // centre grid of the spatial bucketing: kCells^2 = 4 * kThreads
 
 constexpr unsigned kHasUpper = 1u, kHasLower = 2u, kSupp = 4u, kAlive = 8u, kKill = 16u;
 
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
     __shared__ int s_cond;
     __shared__ int s_base;
     __shared__ int s_wave[kWaves];
+    __shared__ int s_hist[kCells * kCells];
 
     const int b = blockIdx.x;
     const int cap = p.cap;
@@ -304,6 +306,54 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
         im.act[t] = t;
     }
     __syncthreads();
+
+    // Physical order of the active list.  Results of the union merge do not depend on it (ranks come
+    // from the keys; min / max / OR are order independent), so the boxes are bucketed by the grid cell of
+    // their centre: all candidates of a word predict nearly the same box and land in the same cell,
+    // which makes the 64-entry tiles spatially tight and the tile-bound pruning effective.  The average
+    // merge sums in list order, so it keeps the input order to stay reproducible bit for bit.
+    if (p.merge_method == OCRHIP_MERGE_UNION && n > 256) {
+        for (int i = threadIdx.x; i < kCells * kCells; i += kThreads) s_hist[i] = 0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < n; t += kThreads) {
+            const float4 bx = im.cur[t];
+            const float cx = 0.5f * (bx.x + bx.z), cy = 0.5f * (bx.y + bx.w);
+            const int ix = (cx == cx) ? (int)fminf(fmaxf(cx * kCells, 0.f), (float)(kCells - 1)) : 0;
+            const int iy = (cy == cy) ? (int)fminf(fmaxf(cy * kCells, 0.f), (float)(kCells - 1)) : 0;
+            const int cell = iy * kCells + ix;
+            im.act2[t] = cell;
+            atomicAdd(&s_hist[cell], 1);
+        }
+        __syncthreads();
+        // exclusive scan of the histogram: 4 cells per thread
+        {
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const int c0 = threadIdx.x * 4;
+            const int h0 = s_hist[c0], h1 = s_hist[c0 + 1], h2 = s_hist[c0 + 2], h3 = s_hist[c0 + 3];
+            const int tot = h0 + h1 + h2 + h3;
+            int incl = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            if (lane == 63) s_wave[wave] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += s_wave[w];
+            const int excl = base + incl - tot;
+            s_hist[c0] = excl;
+            s_hist[c0 + 1] = excl + h0;
+            s_hist[c0 + 2] = excl + h0 + h1;
+            s_hist[c0 + 3] = excl + h0 + h1 + h2;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < n; t += kThreads) {
+            const int pos = atomicAdd(&s_hist[im.act2[t]], 1);
+            im.act[pos] = t;
+        }
+        __syncthreads();
+    }
 
     const bool cull_merge = p.merge_thr > 0.f;
     const int max_iter = p.max_iter > 0 ? p.max_iter : n;

@@ -8,11 +8,11 @@
 // The input projection for all time steps is one flat GEMM (conv_mfma.hip); this file adds the
 // recurrent product on the f32 matrix cores and the gate arithmetic.
 //
-// lstm_step tiling: a workgroup owns 32 sequences x 32 hidden units x 4 gates; its 4 waves split
-// the 256-deep reduction in 4 slices of 64 and meet in LDS, wave 0 finishes the cell.  Operands go
-// straight from L2 to registers in MFMA layout (16 bytes per lane; W_hh is used in checkpoint
-// layout (4H, H) unchanged), there is no reuse inside a step that LDS staging could serve.
-// The step is latency bound (128 dependent-free MFMAs per wave + one LDS exchange), not HBM bound.
+// lstm_step tiling: a workgroup owns 64 sequences x 32 hidden units x 4 gates, one gate per wave; the
+// operands are staged through LDS with full-line coalesced loads (W_hh is used in checkpoint layout
+// (4H, H) unchanged) and the four gates of an element are exchanged through LDS before the cell update.
+// One launch per time step covers both directions and every sequence that is still running; the step
+// is bound by the f32 MFMA rate and the L2 -> LDS re-read of W_hh by every sequence tile.
 #include "common.h"
 
 namespace ocrhip {
@@ -48,81 +48,115 @@ struct LstmArgs {
     float* h_next;           // (2, n, 256)
     float* c_state;          // (2, n, 256)
     float* out;              // (n, T, 512)
-    int n, T, step;
+    const int* seq_T;        // ragged mode: time steps of each sequence (non-decreasing), else nullptr
+    const int* seq_row0;     // ragged mode: first row of each sequence in the flat (sum T, .) matrices
+    int n, T, step, first;   // first = first sequence still active at this step (ragged mode)
 };
 
-// grid (ceil(n/32), 8, 2), block 256
-__global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
-    __shared__ float red[3 * 4 * 16 * 64];     // partial sums of waves 1..3: [wave-1][gate][v][lane]
+constexpr int kSeqTile = 64;     // sequences per workgroup
+constexpr int kLds = 64 + 4;     // floats per staged row (64 k values + pad: conflict-free ds_read_b128)
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// grid (ceil(active/64), 8, 2), block 256.  Workgroup tile: 64 sequences x 32 hidden units x 4 gates;
+// wave g owns gate g (two 32x32 accumulators, full K = 256).  h_{t-1} and W_hh are staged through LDS in
+// K chunks of 64 with fully coalesced 16-byte loads (a row's 256 bytes by 16 consecutive lanes); the next
+// chunk is prefetched into registers during the MFMAs.  The four gates of an element meet in LDS.
+__global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[kSeqTile * kLds];        // h_{t-1} chunk
+    __shared__ __attribute__((aligned(16))) float Bs[4 * 32 * kLds];          // W_hh chunk, rows = gate*32 + unit
+    float* gates = Bs;                                                        // reused after the K loop: [gate][r][v][lane]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int s0 = blockIdx.x * 32, u0 = blockIdx.y * 32, dir = blockIdx.z;
-    const int t = dir ? (a.T - 1 - a.step) : a.step;
+    const int s0 = a.first + blockIdx.x * kSeqTile, u0 = blockIdx.y * 32, dir = blockIdx.z;
     const int n = a.n;
 
-    floatx16 acc[4];
+    floatx16 acc[2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[g][v] = 0.0f;
+        for (int v = 0; v < 16; ++v) acc[r][v] = 0.0f;
 
     if (a.step > 0) {
-        const int kbase = wave * 64;
-        const int seq = s0 + li;
-        const float* hrow = a.h_prev + ((int64_t)dir * n + min(seq, n - 1)) * kHidden + kbase + lh * 4;
-        const float* wrow = a.whh[dir] + ((int64_t)(u0 + li)) * kHidden + kbase + lh * 4;
-        const bool seq_ok = seq < n;
+        // staging map: 16 lanes per row (16 x float4 = 64 floats)
+        const int srow = tid >> 4, scol = (tid & 15) * 4;
+        float4 ra[4], rb[8];
+        auto load_chunk = [&](int kc) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float4 av = *reinterpret_cast<const float4*>(hrow + q * 8);
-            if (!seq_ok) av = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float avv[4] = {av.x, av.y, av.z, av.w};
+            for (int i = 0; i < 4; ++i) {                 // 64 sequence rows
+                const int seq = s0 + srow + i * 16;
+                ra[i] = (seq < n) ? *reinterpret_cast<const float4*>(a.h_prev + ((int64_t)dir * n + seq) * kHidden + kc * 64 + scol)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 bv = *reinterpret_cast<const float4*>(wrow + (int64_t)g * kHidden * kHidden + q * 8);
-                const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+            for (int i = 0; i < 8; ++i) {                 // 128 weight rows: gate = row / 32, unit = row % 32
+                const int row = srow + i * 16;
+                rb[i] = *reinterpret_cast<const float4*>(a.whh[dir] + ((int64_t)(row >> 5) * kHidden + u0 + (row & 31)) * kHidden + kc * 64 + scol);
+            }
+        };
+        auto store_chunk = [&]() {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[k], bvv[k], acc[g], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[(srow + i * 16) * kLds + scol]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&Bs[(srow + i * 16) * kLds + scol]) = rb[i];
+        };
+        load_chunk(0);
+        store_chunk();
+        __syncthreads();
+        for (int kc = 0; kc < 4; ++kc) {
+            if (kc + 1 < 4) load_chunk(kc + 1);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4*>(&Bs[(wave * 32 + li) * kLds + q * 8 + lh * 4]);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(&As[(r * 32 + li) * kLds + q * 8 + lh * 4]);
+                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv[k], acc[r], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (kc + 1 < 4) {
+                store_chunk();
+                __syncthreads();
             }
         }
-        if (wave > 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) red[(((wave - 1) * 4 + g) * 16 + v) * 64 + lane] = acc[g][v];
-        }
     }
+    // gate exchange: [gate][r][v][lane]
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) gates[((wave * 2 + r) * 16 + v) * 64 + lane] = acc[r][v];
     __syncthreads();
-    if (wave != 0) return;
 
+    // element (r, v, lane): sequence s0 + r*32 + (v&3) + 8*(v>>2) + 4*(lane>>5), unit u0 + (lane&31);
+    // wave w finishes v in [4w, 4w+4) of both r
     const int u = u0 + li;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int seq = s0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-        if (seq >= n) continue;
-        float z[4];
-        const float* xw = a.xw[dir] + ((int64_t)seq * a.T + t) * (4 * kHidden) + u;
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float s = acc[g][v];
-            if (a.step > 0) {
-                s += red[((0 * 4 + g) * 16 + v) * 64 + lane];
-                s += red[((1 * 4 + g) * 16 + v) * 64 + lane];
-                s += red[((2 * 4 + g) * 16 + v) * 64 + lane];
-            }
-            z[g] = xw[g * kHidden] + s;
+        for (int vv = 0; vv < 4; ++vv) {
+            const int v = wave * 4 + vv;
+            const int seq = s0 + r * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            if (seq >= n) continue;
+            const int Ts = a.seq_T ? a.seq_T[seq] : a.T;
+            const int64_t row = (a.seq_row0 ? (int64_t)a.seq_row0[seq] : (int64_t)seq * a.T) + (dir ? (Ts - 1 - a.step) : a.step);
+            const float* xw = a.xw[dir] + row * (4 * kHidden) + u;
+            float z[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) z[g] = xw[g * kHidden] + gates[((g * 2 + r) * 16 + v) * 64 + lane];
+            const int64_t sidx = ((int64_t)dir * n + seq) * kHidden + u;
+            const float c_prev = (a.step > 0) ? a.c_state[sidx] : 0.0f;
+            const float c = sigmoidf_(z[1]) * c_prev + sigmoidf_(z[0]) * tanhf(z[2]);
+            const float hval = sigmoidf_(z[3]) * tanhf(c);
+            a.c_state[sidx] = c;
+            a.h_next[sidx] = hval;
+            a.out[row * (2 * kHidden) + dir * kHidden + u] = hval;
         }
-        const int64_t sidx = ((int64_t)dir * n + seq) * kHidden + u;
-        const float c_prev = (a.step > 0) ? a.c_state[sidx] : 0.0f;
-        const float c = sigmoidf_(z[1]) * c_prev + sigmoidf_(z[0]) * tanhf(z[2]);
-        const float hval = sigmoidf_(z[3]) * tanhf(c);
-        a.c_state[sidx] = c;
-        a.h_next[sidx] = hval;
-        a.out[((int64_t)seq * a.T + t) * (2 * kHidden) + dir * kHidden + u] = hval;
-    }
 }
 
 }  // namespace
@@ -139,13 +173,17 @@ int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipSt
 }
 
 int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, const float* h_prev,
-                     float* h_next, float* c_state, float* out, int n, int T, int step, hipStream_t s) {
+                     float* h_next, float* c_state, float* out, int n, int T, int step, const int* seq_T,
+                     const int* seq_row0, int first, hipStream_t s) {
     OCR_REQUIRE(xw_f && xw_b && whh_f && whh_b && h_prev && h_next && c_state && out, "lstm_step: null argument");
-    OCR_REQUIRE(n > 0 && T > 0 && step >= 0 && step < T, "lstm_step: bad sizes n=%d T=%d step=%d", n, T, step);
+    OCR_REQUIRE(n > 0 && T > 0 && step >= 0 && step < T && first >= 0 && first < n,
+                "lstm_step: bad sizes n=%d T=%d step=%d first=%d", n, T, step, first);
+    OCR_REQUIRE((seq_T == nullptr) == (seq_row0 == nullptr), "lstm_step: seq_T and seq_row0 go together");
     LstmArgs a;
+    a.seq_T = seq_T; a.seq_row0 = seq_row0; a.first = first;
     a.xw[0] = xw_f; a.xw[1] = xw_b; a.whh[0] = whh_f; a.whh[1] = whh_b;
     a.h_prev = h_prev; a.h_next = h_next; a.c_state = c_state; a.out = out; a.n = n; a.T = T; a.step = step;
-    dim3 grid((n + 31) / 32, kHidden / 32, 2);
+    dim3 grid((n - first + kSeqTile - 1) / kSeqTile, kHidden / 32, 2);
     hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;

@@ -200,6 +200,26 @@ class HipContext:
                                            _ptr(scores), _stream()))
         return {'logits': logits, 'tokens': tokens, 'scores': scores}
 
+    def crnn_forward_packed(self, packed, out_w, want_logits=False, compute_dtype=F32):
+        """packed: flat float32 GPU buffer of (64, out_w[i]) planes back to back; out_w: host int32 array,
+        non-decreasing -> dict(tokens (n,Tmax) int32, scores (n,), lengths (n,), [logits (sum T, V)])."""
+        assert packed.is_cuda and packed.dtype == torch.float32 and packed.is_contiguous()
+        out_w = np.ascontiguousarray(out_w, dtype=np.int32)
+        n = int(out_w.shape[0])
+        if int(packed.numel()) < 64 * int(out_w.astype(np.int64).sum()):
+            raise ValueError('crnn_forward_packed: packed buffer is smaller than the crops it should hold')
+        t_all = out_w // 4 - 1
+        tmax, rows = int(t_all.max()), int(t_all.astype(np.int64).sum())
+        dev = packed.device
+        tokens = torch.empty((n, tmax), dtype=torch.int32, device=dev)
+        scores = torch.empty((n,), dtype=torch.float32, device=dev)
+        lengths = torch.empty((n,), dtype=torch.int32, device=dev)
+        logits = torch.empty((rows, self.vocab_size), dtype=torch.float32, device=dev) if want_logits else None
+        check(self.lib.ocrhip_crnn_forward_packed(self._h, _ptr(packed), ctypes.c_void_p(out_w.ctypes.data), n,
+                                                  compute_dtype, tmax, _ptr(logits), _ptr(tokens), _ptr(scores),
+                                                  _ptr(lengths), _stream()))
+        return {'tokens': tokens, 'scores': scores, 'lengths': lengths, 'logits': logits}
+
     def crnn_activation(self, name):
         return self._activation(self.lib.ocrhip_crnn_get_activation, name)
 

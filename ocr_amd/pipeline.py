@@ -49,76 +49,122 @@ class OcrPipeline:
                               nms_threshold=self.nms_threshold, merge_method=self.merge_method)
         return maps, dec, kept
 
-    # ---- recognition ------------------------------------------------------------------------
-    def recognise(self, images, boxes_per_image):
-        """images (B,H,W,3) uint8 GPU; boxes_per_image: list of (m_b,4) float32 relative xyxy (host).
+    # ---- the three stages of a batch; each one only enqueues GPU work and small async copies ------
+    KEEP_CAP = 2048          # kept boxes per page copied to the host in the first shot
 
-        Returns per image: list of dict(box, text, score) for the boxes that give a valid crop."""
+    def _stage_detect(self, images, maps_override=None):
+        """Enqueue detection and the device->host copy of the kept boxes (pinned memory + event)."""
+        B = images.shape[0]
+        _, _, kept = self.detect(images, maps_override)
+        k = min(self.KEEP_CAP, kept['boxes'].shape[1])
+        h_boxes = torch.empty((B, k, 4), dtype=torch.float32, pin_memory=True)
+        h_counts = torch.empty((B,), dtype=torch.int32, pin_memory=True)
+        h_boxes.copy_(kept['boxes'][:, :k], non_blocking=True)
+        h_counts.copy_(kept['counts'], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return {'images': images, 'kept': kept, 'h_boxes': h_boxes, 'h_counts': h_counts, 'boxes_ready': ev}
+
+    def _stage_recognise(self, st):
+        """Wait for the boxes, do the host size arithmetic, enqueue crop + recogniser + token copy."""
+        st['boxes_ready'].synchronize()
+        images = st['images']
         B, H, W, _ = images.shape
-        rects, inter, out_w, box_img, box_idx = [], [], [], [], []
-        for b, boxes in enumerate(boxes_per_image):
-            plan = S.plan_crops(boxes, H, W)
-            rects.append(plan['rects']), inter.append(plan['inter']), out_w.append(plan['out_w'])
-            box_img.append(np.full(len(plan['index']), b, dtype=np.int32))
-            box_idx.append(plan['index'])
-        rects, inter, out_w = np.concatenate(rects), np.concatenate(inter), np.concatenate(out_w)
-        box_img, box_idx = np.concatenate(box_img), np.concatenate(box_idx)
-        results = [[] for _ in range(B)]
+        counts = st['h_counts'].numpy()
+        if int(counts.max(initial=0)) > st['h_boxes'].shape[1]:          # rare: more kept boxes than KEEP_CAP
+            boxes = st['kept']['boxes'][:, :int(counts.max())].cpu().numpy()
+        else:
+            boxes = st['h_boxes'].numpy()
+        per_image = [boxes[b, :int(counts[b])].copy() for b in range(B)]
+        st['per_image'] = per_image
+        st['kept'] = None
+        plans = [S.plan_crops(bx, H, W) for bx in per_image]
+        rects = np.concatenate([p['rects'] for p in plans])
+        inter = np.concatenate([p['inter'] for p in plans])
+        out_w = np.concatenate([p['out_w'] for p in plans])
+        box_idx = np.concatenate([p['index'] for p in plans])
+        box_img = np.concatenate([np.full(len(p['index']), b, dtype=np.int32) for b, p in enumerate(plans)])
         n = len(rects)
+        st['n'] = n
         if n == 0:
-            return results
-        # crops grouped by padded width: each group is one recogniser batch
+            return st
+        # crops sorted by padded width: the recogniser runs its feature extractor once per width and its
+        # recurrent / dense / CTC part once over all sequences
         order = np.argsort(out_w, kind='stable')
         rects, inter, out_w, box_img, box_idx = rects[order], inter[order], out_w[order], box_img[order], box_idx[order]
         off = np.concatenate([[0], np.cumsum(64 * out_w.astype(np.int64))])
         dev = images.device
-        meta = torch.from_numpy(np.concatenate([rects.reshape(-1), inter.reshape(-1), out_w, box_img]).astype(np.int32)).to(dev)
+        h_meta = torch.from_numpy(np.concatenate([rects.reshape(-1), inter.reshape(-1), out_w, box_img]).astype(np.int32)).pin_memory()
+        h_off = torch.from_numpy(off[:-1].astype(np.int64)).pin_memory()
+        meta = h_meta.to(dev, non_blocking=True)
+        d_off = h_off.to(dev, non_blocking=True)
         d_rects, d_inter = meta[:4 * n].view(n, 4), meta[4 * n:6 * n].view(n, 2)
         d_out_w, d_box_img = meta[6 * n:7 * n], meta[7 * n:8 * n]
-        d_off = torch.from_numpy(off[:-1].astype(np.int64)).to(dev)
         packed = self.ctx.crop_resize_pack(images, d_rects, d_box_img, d_inter, d_out_w, d_off, int(off[-1]))
-        tokens_out, scores_out = [], []
-        widths, starts = np.unique(out_w, return_index=True)
-        bounds = list(starts) + [n]
-        for gi, wpad in enumerate(widths):
-            lo, hi = bounds[gi], bounds[gi + 1]
-            step = max(1, self.max_crop_elems // int(wpad))
-            for c0 in range(lo, hi, step):
-                c1 = min(hi, c0 + step)
-                crops = packed[off[c0]:off[c1]].view(c1 - c0, 64, int(wpad))
-                out = self.ctx.crnn_forward(crops, want_logits=False, want_tokens=True, compute_dtype=F32)
-                tokens_out.append(out['tokens']), scores_out.append(out['scores'])
-        scores = torch.cat(scores_out).cpu().numpy()
-        tokens = [t.cpu().numpy() for t in tokens_out]
-        k = 0
-        for tk in tokens:
-            for row in tk:
-                b = int(box_img[k])
-                results[b].append({'box_index': int(box_idx[k]), 'text': self.tokenizer.decode(row),
-                                   'score': float(scores[k])})
-                k += 1
-        for b in range(B):
-            results[b].sort(key=lambda r: r['box_index'])
-        return results
+        out = self.ctx.crnn_forward_packed(packed, out_w)
+        h_tokens = torch.empty(out['tokens'].shape, dtype=torch.int32, pin_memory=True)
+        h_scores = torch.empty(out['scores'].shape, dtype=torch.float32, pin_memory=True)
+        h_tokens.copy_(out['tokens'], non_blocking=True)
+        h_scores.copy_(out['scores'], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st.update(h_tokens=h_tokens, h_scores=h_scores, tokens_ready=ev, box_img=box_img, box_idx=box_idx,
+                  _keep=(h_meta, h_off, meta, d_off, packed, out))
+        return st
+
+    def _stage_strings(self, st):
+        """Wait for the tokens and turn them into strings."""
+        per_image = st['per_image']
+        B = len(per_image)
+        out = [{'boxes': per_image[b], 'texts': [''] * len(per_image[b]), 'scores': [None] * len(per_image[b]),
+                'valid': np.zeros(len(per_image[b]), dtype=bool)} for b in range(B)]
+        if st['n'] == 0:
+            return out
+        st['tokens_ready'].synchronize()
+        tokens, scores = st['h_tokens'].numpy(), st['h_scores'].numpy()
+        box_img, box_idx = st['box_img'], st['box_idx']
+        decode = self.tokenizer.decode
+        for k in range(st['n']):
+            o, i = out[int(box_img[k])], int(box_idx[k])
+            o['texts'][i] = decode(tokens[k])
+            o['scores'][i] = float(scores[k])
+            o['valid'][i] = True
+        return out
 
     # ---- end to end -------------------------------------------------------------------------
     def __call__(self, images, maps_override=None):
-        """images (B,H,W,3) uint8 GPU -> list (per page) of dict(boxes (m,4) f32, texts, scores)."""
+        """images (B,H,W,3) uint8 GPU -> list (per page) of dict(boxes (m,4) f32, texts, scores, valid)."""
+        return self._stage_strings(self._stage_recognise(self._stage_detect(images, maps_override)))
+
+    def run_batches(self, batches):
+        """Streams batches through the three stages, software-pipelined: while the GPU works on the
+        detection of batch i+1 the host does the size arithmetic of batch i and decodes the strings of
+        batch i-1, so neither side waits for the other.  `batches` yields (images, maps_override);
+        results are yielded in order."""
+        detected, recognised = None, None
+        for images, maps_override in batches:
+            nxt = self._stage_detect(images, maps_override)
+            if recognised is not None:
+                yield self._stage_strings(recognised)
+                recognised = None
+            if detected is not None:
+                recognised = self._stage_recognise(detected)
+            detected = nxt
+        if recognised is not None:
+            yield self._stage_strings(recognised)
+        if detected is not None:
+            yield self._stage_strings(self._stage_recognise(detected))
+
+    def recognise(self, images, boxes_per_image):
+        """images (B,H,W,3) uint8 GPU; boxes_per_image: list of (m_b,4) float32 relative xyxy (host)
+        -> per image: dict(boxes, texts, scores, valid)."""
         B = images.shape[0]
-        _, _, kept = self.detect(images, maps_override)
-        counts = kept['counts'].cpu().numpy()
-        mx = int(counts.max()) if B else 0
-        boxes = kept['boxes'][:, :max(mx, 1)].cpu().numpy()
-        per_image = [boxes[b, :int(counts[b])] for b in range(B)]
-        rec = self.recognise(images, per_image)
-        out = []
-        for b in range(B):
-            texts = [''] * len(per_image[b])
-            scores = [None] * len(per_image[b])
-            valid = np.zeros(len(per_image[b]), dtype=bool)
-            for r in rec[b]:
-                texts[r['box_index']] = r['text']
-                scores[r['box_index']] = r['score']
-                valid[r['box_index']] = True
-            out.append({'boxes': per_image[b], 'texts': texts, 'scores': scores, 'valid': valid})
-        return out
+        k = max(1, max(len(b) for b in boxes_per_image))
+        h_boxes = torch.zeros((B, k, 4), dtype=torch.float32)
+        for b, bx in enumerate(boxes_per_image):
+            h_boxes[b, :len(bx)] = torch.from_numpy(np.ascontiguousarray(bx, dtype=np.float32))
+        ev = torch.cuda.Event()
+        ev.record()
+        st = {'images': images, 'kept': None, 'h_boxes': h_boxes, 'boxes_ready': ev,
+              'h_counts': torch.tensor([len(b) for b in boxes_per_image], dtype=torch.int32)}
+        return self._stage_strings(self._stage_recognise(st))

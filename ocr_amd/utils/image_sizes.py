@@ -55,23 +55,33 @@ def resolve_slices(abs_boxes, image_h, image_w):
     return out, valid
 
 
+def _resolve_index(v, size):
+    """Vectorised `slice(v, ...).indices(size)` for one bound (step 1): negative wraps once, then clamps."""
+    v = np.where(v < 0, v + size, v)
+    return np.clip(v, 0, size)
+
+
 def plan_crops(boxes_rel, image_h, image_w, height=64, multiple=64):
-    """Everything the crop kernel needs for the boxes of one image.
+    """Everything the crop kernel needs for the boxes of one image (vectorised over the boxes).
 
     Returns dict(rects (m,4) int32, inter (m,2) int32, out_w (m,) int32, index (m,) indices of the
     boxes that give a non-empty network input)."""
-    rects, valid = resolve_slices(relative_to_absolute(boxes_rel, image_h, image_w), image_h, image_w)
-    keep, inter, out_w = [], [], []
-    for i in np.nonzero(valid)[0]:
-        ch, cw = int(rects[i, 3] - rects[i, 1]), int(rects[i, 2] - rects[i, 0])
-        oh, ow = crnn_output_size(ch, cw, height, multiple)
-        if ow <= 0:
-            continue
-        ih, iw = crnn_intermediate_size(ch, cw, oh, ow)
-        if ih <= 0 or iw <= 0:
-            continue
-        keep.append(i), inter.append((ih, iw)), out_w.append(ow)
-    keep = np.array(keep, dtype=np.int64)
-    return {'rects': rects[keep].astype(np.int32).reshape(-1, 4),
-            'inter': np.array(inter, dtype=np.int32).reshape(-1, 2),
-            'out_w': np.array(out_w, dtype=np.int32), 'index': keep}
+    ab = relative_to_absolute(boxes_rel, image_h, image_w).astype(np.int64)
+    x0, x1 = _resolve_index(ab[:, 0], image_w), _resolve_index(ab[:, 2], image_w)
+    y0, y1 = _resolve_index(ab[:, 1], image_h), _resolve_index(ab[:, 3], image_h)
+    cw, ch = x1 - x0, y1 - y0
+    valid = (cw > 0) & (ch > 0)
+    chs, cws = np.maximum(ch, 1), np.maximum(cw, 1)
+    # get_output_size: ratio = max(height / h, -1 / w) in float64, W' = int32(w * ratio), next multiple
+    ratio = np.maximum(np.float64(height) / chs.astype(np.float64), -1.0 / cws.astype(np.float64))
+    w_out = (cws.astype(np.float64) * ratio).astype(np.int32).astype(np.int64)
+    w_out = np.where(w_out % multiple != 0, (w_out // multiple + 1) * multiple, w_out)
+    # resize_image: intermediate = int32(float32(hw) * min(float32(out) / float32(hw)))
+    hf, wf = chs.astype(np.float32), cws.astype(np.float32)
+    r32 = np.minimum(np.float32(height) / hf, w_out.astype(np.float32) / wf)
+    ih, iw = (hf * r32).astype(np.int32), (wf * r32).astype(np.int32)
+    valid &= (w_out > 0) & (ih > 0) & (iw > 0)
+    keep = np.nonzero(valid)[0]
+    rects = np.stack([x0, y0, x1, y1], axis=1)[keep].astype(np.int32)
+    return {'rects': rects.reshape(-1, 4), 'inter': np.stack([ih, iw], axis=1)[keep].astype(np.int32).reshape(-1, 2),
+            'out_w': w_out[keep].astype(np.int32), 'index': keep.astype(np.int64)}

@@ -69,3 +69,32 @@ def test_crnn_forward_matches_oracle(ctx, n, Wpad, V):
     rt, rs = octc.ctc_greedy(got, None, 0)
     np.testing.assert_array_equal(out['tokens'].cpu().numpy(), rt)
     np.testing.assert_array_equal(out['scores'].cpu().numpy(), rs)
+
+
+def test_crnn_forward_packed_ragged_matches_per_row_oracle(ctx):
+    """All widths in one call == the reference's one-forward-per-row + pad_batch + ctc_decode(lengths)."""
+    from oracle import ctc as octc
+    V = 97
+    params = nets.init_crnn_params(vocab_size=V, seed=7)
+    ctx.crnn_load_weights(params)
+    rng = np.random.default_rng(3)
+    widths = np.array([64] * 3 + [128] * 35 + [192] * 2 + [320], dtype=np.int32)
+    crops = [rng.uniform(-1, 1, (64, int(w))).astype(np.float32) for w in widths]
+    packed = torch.from_numpy(np.concatenate([c.reshape(-1) for c in crops])).cuda()
+    out = ctx.crnn_forward_packed(packed, widths, want_logits=True)
+    torch.cuda.synchronize()
+    logits = out['logits'].cpu().numpy()
+    T = widths // 4 - 1
+    np.testing.assert_array_equal(out['lengths'].cpu().numpy(), T)
+    row0 = np.concatenate([[0], np.cumsum(T)])
+    padded = np.zeros((len(widths), int(T.max()), V), np.float32)
+    for i, c in enumerate(crops):
+        ref = nets.crnn_forward(params, c[None, :, :, None])[0].numpy()
+        got = logits[row0[i]:row0[i + 1]]
+        _close(got, ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+        padded[i, :T[i]] = got
+    rt, rs = octc.ctc_greedy(padded, T.astype(np.int32), 0)
+    np.testing.assert_array_equal(out['tokens'].cpu().numpy(), rt)
+    np.testing.assert_array_equal(out['scores'].cpu().numpy(), rs)
+    with pytest.raises(ValueError):
+        ctx.crnn_forward_packed(packed, widths[::-1].copy())          # widths must be non-decreasing
