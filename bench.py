@@ -67,14 +67,10 @@ def cpu_baseline(images, maps, east_params, crnn_params, n_pages):
 
 def main():
     args = parse()
-    rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    from ocr_amd.dist import init_from_env, max_over_ranks
+    rank, world, dist = init_from_env('nccl', torch.device('cuda', local_rank))     # RCCL when launched by torchrun
 
     from ocr_amd import synth
     from ocr_amd.pipeline import OcrPipeline
@@ -113,11 +109,9 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = pipe.ctx.profile_collect()
     pipe.ctx.profile_enable(False)
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     if dist is not None:
         dist.barrier()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist, torch.device('cuda', local_rank))
 
     if rank == 0:
         pages = world * args.steps * B

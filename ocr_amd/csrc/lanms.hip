@@ -25,6 +25,8 @@
 // Suppressed boxes leave the active list after every iteration, so the cost is dominated by the
 // first iteration.  This stage is compute/latency bound (N^2 pair tests on ~20 B per box), not HBM
 // bound.
+#include <algorithm>
+
 #include "common.h"
 
 namespace ocrhip {
@@ -46,6 +48,7 @@ struct Image {
     int* act2;
     float4* bounds;       // per 64-entry tile of act: (min x1, min y1, max x2, max y2)
     int* kept;            // indices of the kept boxes
+    int* hdr;             // [0] = loop condition published by the split first iteration
 };
 
 __device__ __forceinline__ unsigned order_key(float s) {
@@ -98,13 +101,13 @@ __device__ void build_bounds(const Image& im, const float4* boxes, const int* ac
 // MODE 3: NMS pass B     (writes kKill; sets *cond)
 template <int MODE>
 __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr, bool cull, int merge_method,
-                           int* cond) {
+                           int* cond, int tile0 = 0, int tile_stride = kWaves) {
     n_act = __builtin_amdgcn_readfirstlane(n_act);       // wave-uniform by construction
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ntiles = (n_act + 63) >> 6;
     const float4* boxes = im.cur;
 
-    for (int T = wave; T < ntiles; T += kWaves) {
+    for (int T = tile0 + wave; T < ntiles; T += tile_stride) {
         const int e = T * 64 + lane;
         const bool t_valid = e < n_act;
         const int t = t_valid ? act[e] : 0;
@@ -261,6 +264,11 @@ struct Params {
     int* n_iter;
     char* ws;
     size_t ws_stride;      // bytes per image
+    // 0: everything in one launch.  The first merge iteration (all N candidates) dominates the cost, so for
+    // large capacities it is spread over several workgroups per image by separate launches:
+    // 1 = set-up (+ tile bounds), 2 = pass A and 3 = pass B on gridDim.y workgroups per image,
+    // 4 = the rest (compaction, further iterations, NMS, outputs) on one workgroup per image.
+    int phase;
 };
 
 __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
     const int64_t o = (int64_t)b * cap;
 
     if (n <= 0) {
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && (p.phase == 0 || p.phase == 4)) {
             p.out_counts[b] = 0;
             if (p.n_iter) p.n_iter[b] = 0;
         }
@@ -286,6 +294,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
     {
         char* w = p.ws + (size_t)b * p.ws_stride;
         const size_t c = (size_t)cap;
+        im.hdr = reinterpret_cast<int*>(w);                    w += 64;
         im.cur = reinterpret_cast<float4*>(w);                 w += c * sizeof(float4);
         im.nxt = reinterpret_cast<float4*>(w);                 w += c * sizeof(float4);
         im.bounds = reinterpret_cast<float4*>(w);              w += ((c + 63) / 64) * sizeof(float4);
@@ -296,7 +305,18 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
         im.kept = reinterpret_cast<int*>(w);
     }
 
+    const bool cull_merge = p.merge_thr > 0.f;
+    if (p.phase == 2 || p.phase == 3) {      // one pass of the first iteration, tiles strided over gridDim.y workgroups
+        const int tile0 = blockIdx.y * kWaves, stride = gridDim.y * kWaves;
+        if (p.phase == 2)
+            scan_pairs<0>(im, im.act, n, p.merge_thr, cull_merge, p.merge_method, im.hdr, tile0, stride);
+        else
+            scan_pairs<1>(im, im.act, n, p.merge_thr, cull_merge, p.merge_method, im.hdr, tile0, stride);
+        return;
+    }
+
     const float4* in_boxes = reinterpret_cast<const float4*>(p.xyxy) + o;
+    if (p.phase != 4)
     for (int t = threadIdx.x; t < n; t += kThreads) {
         const float4 bx = in_boxes[t];
         im.cur[t] = bx;
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
     // their centre: all candidates of a word predict nearly the same box and land in the same cell,
     // which makes the 64-entry tiles spatially tight and the tile-bound pruning effective.  The average
     // merge sums in list order, so it keeps the input order to stay reproducible bit for bit.
-    if (p.merge_method == OCRHIP_MERGE_UNION && n > 256) {
+    if (p.phase != 4 && p.merge_method == OCRHIP_MERGE_UNION && n > 256) {
         for (int i = threadIdx.x; i < kCells * kCells; i += kThreads) s_hist[i] = 0;
         __syncthreads();
         for (int t = threadIdx.x; t < n; t += kThreads) {
@@ -355,20 +375,28 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
         __syncthreads();
     }
 
-    const bool cull_merge = p.merge_thr > 0.f;
+    if (p.phase == 1) {                      // set-up launch: the passes of the first iteration follow as launches
+        if (threadIdx.x == 0) im.hdr[0] = 0;
+        build_bounds(im, im.cur, im.act, n);
+        return;
+    }
     const int max_iter = p.max_iter > 0 ? p.max_iter : n;
     int n_act = n;
     int iter = 0;
     bool cond = true;
     while (cond && iter < max_iter) {
-        if (threadIdx.x == 0) s_cond = 0;
-        build_bounds(im, im.cur, im.act, n_act);
-        __syncthreads();
-        scan_pairs<0>(im, im.act, n_act, p.merge_thr, cull_merge, p.merge_method, &s_cond);
-        __syncthreads();
-        scan_pairs<1>(im, im.act, n_act, p.merge_thr, cull_merge, p.merge_method, &s_cond);
-        __syncthreads();
-        cond = s_cond != 0;
+        if (p.phase == 4 && iter == 0) {
+            cond = im.hdr[0] != 0;           // passes A and B of this iteration ran as separate launches
+        } else {
+            if (threadIdx.x == 0) s_cond = 0;
+            build_bounds(im, im.cur, im.act, n_act);
+            __syncthreads();
+            scan_pairs<0>(im, im.act, n_act, p.merge_thr, cull_merge, p.merge_method, &s_cond);
+            __syncthreads();
+            scan_pairs<1>(im, im.act, n_act, p.merge_thr, cull_merge, p.merge_method, &s_cond);
+            __syncthreads();
+            cond = s_cond != 0;
+        }
         // cur <-> nxt; suppressed boxes leave the active list (they are all-zero from now on)
         float4* tmp = im.cur; im.cur = im.nxt; im.nxt = tmp;
         if (cull_merge) {
@@ -482,7 +510,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
 
 size_t ws_bytes_per_image(int cap) {
     const size_t c = (size_t)cap;
-    size_t bytes = 2 * c * sizeof(float4) + ((c + 63) / 64) * sizeof(float4) + 5 * c * sizeof(int);
+    size_t bytes = 64 + 2 * c * sizeof(float4) + ((c + 63) / 64) * sizeof(float4) + 5 * c * sizeof(int);
     return (bytes + 255) & ~(size_t)255;
 }
 
@@ -513,7 +541,23 @@ int launch_lanms(ocrhip_ctx* h, const float* xyxy, const float* scores, const in
     p.merged = merged; p.keep = keep; p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_src = out_src;
     p.out_counts = out_counts; p.n_iter = n_iter;
     ProfScope prof("lanms", 0.0, 0.0, s);
-    hipLaunchKernelGGL(lanms_kernel, dim3(B), dim3(kThreads), 0, s, p);
+    // workgroups per image for the first iteration: enough tiles to share (64 boxes per wave-tile, 16 waves)
+    // and no more than the chip holds at once
+    int G = std::min(16, std::max(1, 256 / B));
+    if (cap < 4096) G = 1;
+    if (G <= 1) {
+        p.phase = 0;
+        hipLaunchKernelGGL(lanms_kernel, dim3(B), dim3(kThreads), 0, s, p);
+    } else {
+        p.phase = 1;
+        hipLaunchKernelGGL(lanms_kernel, dim3(B), dim3(kThreads), 0, s, p);
+        p.phase = 2;
+        hipLaunchKernelGGL(lanms_kernel, dim3(B, G), dim3(kThreads), 0, s, p);
+        p.phase = 3;
+        hipLaunchKernelGGL(lanms_kernel, dim3(B, G), dim3(kThreads), 0, s, p);
+        p.phase = 4;
+        hipLaunchKernelGGL(lanms_kernel, dim3(B), dim3(kThreads), 0, s, p);
+    }
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }
