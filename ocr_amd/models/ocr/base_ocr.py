@@ -1,9 +1,9 @@
 """`BaseOCR` / `CRNN` with the reference's interface (models/ocr/base_ocr.py:53-255,371-375,
 models/ocr/crnn.py:15-58), running on libocrhip.so.
 
-Differences a caller can observe, all by omission (NotImplementedError, never a silent change):
-`combine=True` (word -> line grouping) and `method='beam_search'` are not built yet, so the
-defaults here are `combine=False`, `method='greedy'`; callbacks / savers / streaming are out of scope.
+Same defaults as the reference (`combine=True`, `method='beam_search'`, 10 beams).  Beam search runs on
+the host from the GPU logits; `method='greedy'` decodes on the GPU.  `box_filters`, `dezoom_factor`,
+callbacks / savers / streaming are not built (NotImplementedError or ignored, never a silent change).
 """
 import logging
 
@@ -93,10 +93,15 @@ class BaseOCR:
             torch.from_numpy(off[:-1].astype(np.int64)).to(dev), int(off[-1]))
         return packed, plan, off
 
-    def recognise_rows(self, image, rows, method='greedy'):
-        """All rows of one image in one go -> (index of valid rows, texts, scores)."""
-        if method != 'greedy':
-            raise NotImplementedError('CTC {} decoding is not available in this build (greedy only)'.format(method))
+    def recognise_rows(self, image, rows, method='greedy', num_beams=10):
+        """All rows of one image in one go -> (index of valid rows, texts, scores).
+
+        method 'greedy': argmax + collapse on the GPU.  method 'beam_search' / 'beam': the logits come
+        back to the host and go through CTC prefix beam search (utils/ctc_beam.py)."""
+        if method == 'beam':
+            method = 'beam_search'
+        if method not in ('greedy', 'beam_search'):
+            raise ValueError('Unknown CTC decoding method : {}'.format(method))
         if image.dtype != np.uint8:
             image = np.clip(np.asarray(image) * 255, 0, 255).astype(np.uint8) if image.dtype.kind == 'f' else image.astype(np.uint8)
         if image.shape[2] == 1:
@@ -106,26 +111,39 @@ class BaseOCR:
         if out is None:
             return [], [], np.zeros((0,), np.float32)
         packed, plan, off = out
-        texts, scores = [None] * len(plan['index']), np.zeros(len(plan['index']), np.float32)
-        for wpad in np.unique(plan['out_w']):
-            sel = np.nonzero(plan['out_w'] == wpad)[0]
-            crops = torch.stack([packed[off[j]:off[j + 1]].view(64, int(wpad)) for j in sel])
-            res = self.ctx.crnn_forward(crops.contiguous(), want_logits=False, want_tokens=True)
+        n = len(plan['index'])
+        order = np.argsort(plan['out_w'], kind='stable')          # the recogniser wants non-decreasing widths
+        widths = plan['out_w'][order]
+        sorted_packed = torch.cat([packed[off[j]:off[j + 1]] for j in order]) if n > 1 else packed
+        res = self.ctx.crnn_forward_packed(sorted_packed, widths, want_logits=(method == 'beam_search'))
+        if method == 'greedy':
             toks, sc = res['tokens'].cpu().numpy(), res['scores'].cpu().numpy()
-            for k, j in enumerate(sel):
-                texts[j] = self.tokenizer.decode(toks[k])
-                scores[j] = sc[k]
+        else:
+            from ...utils.ctc_beam import ctc_beam_search
+            T = widths // 4 - 1
+            row0 = np.concatenate([[0], np.cumsum(T)])
+            flat = res['logits'].cpu().numpy()
+            padded = np.zeros((n, int(T.max()), flat.shape[1]), np.float32)      # pad_batch(pad_value=0.)
+            for k in range(n):
+                padded[k, :T[k]] = flat[row0[k]:row0[k + 1]]
+            toks, sc = ctc_beam_search(padded, T, num_beams=num_beams, blank=self.blank_token_idx)
+        texts, scores = [None] * n, np.zeros(n, np.float32)
+        for k, j in enumerate(order):
+            texts[j] = self.tokenizer.decode(toks[k])
+            scores[j] = sc[k]
         return list(plan['index']), texts, scores
 
-    def infer(self, data, *, detector='east', detector_kwargs={'merge_method': 'union'}, combine=False,
-              box_filters=None, dezoom_factor=1., method='greedy', num_beams=10, num_sentences=1, length_power=.25,
+    def infer(self, data, *, detector='east', detector_kwargs={'merge_method': 'union'}, combine=True,
+              box_filters=None, dezoom_factor=1., method='beam_search', num_beams=10, num_sentences=1, length_power=.25,
               threshold=0., box_callback=None, callbacks=None, predicted=None, overwrite=False, return_output=True,
               **kwargs):
-        """base_ocr.py:98-255.  Returns dict(filename, boxes, ocr=[dict(boxes, rows, text, format, scores)], image)."""
+        """base_ocr.py:98-255.  Returns dict(filename, boxes, ocr=[dict(boxes, rows, text, format, scores)], image).
+
+        With `combine=True` the detected words are grouped into lines and paragraphs first
+        (utils/combination.py) and every line is one recogniser input; the texts of a paragraph are
+        joined with ' \n' like the reference does."""
         if predicted and not overwrite and isinstance(data, str) and data in predicted:
             return predicted[data]
-        if combine:
-            raise NotImplementedError('combine=True (grouping words into lines) is not available in this build')
         if box_filters or dezoom_factor != 1.:
             raise NotImplementedError('box_filters / dezoom_factor are not available in this build')
         filename, image = get_image_data(data)
@@ -138,16 +156,27 @@ class BaseOCR:
         if isinstance(boxes, dict):
             boxes = boxes['boxes']
         boxes = np.asarray(boxes, dtype=np.float32).reshape(-1, 4)
-        index, texts, scores = self.recognise_rows(np.asarray(image), boxes, method=method)
-        n_skipped = len(boxes) - len(index)
-        if n_skipped:
-            logger.warning('Invalid input encountered : %d empty crops skipped', n_skipped)
+        if combine and len(boxes):
+            from ...utils.combination import combine_boxes
+            boxes, _, rows = combine_boxes(boxes, **kwargs)
+            rows = [np.asarray(r, dtype=np.float32).reshape(-1, 4) for r in rows]
+        else:
+            rows = [boxes[i:i + 1] for i in range(len(boxes))]
+        flat_rows = np.concatenate(rows).reshape(-1, 4) if rows else np.zeros((0, 4), np.float32)
+        owner = np.concatenate([np.full(len(r), i) for i, r in enumerate(rows)]) if rows else np.zeros((0,), int)
+        index, texts, scores = self.recognise_rows(np.asarray(image), flat_rows, method=method, num_beams=num_beams)
+        if len(flat_rows) - len(index):
+            logger.warning('Invalid input encountered : %d empty crops skipped', len(flat_rows) - len(index))
         ocr_results = []
-        for k, i in enumerate(index):
-            sc = np.array([scores[k]], dtype=np.float32)
+        for i, rows_i in enumerate(rows):
+            sel = [k for k, j in enumerate(index) if owner[j] == i]
+            if not sel:
+                continue
+            sc = np.array([scores[k] for k in sel], dtype=np.float32)
             if threshold < 0. and np.any(sc < threshold):
                 continue
-            info = {'boxes': boxes[i], 'rows': boxes[i:i + 1], 'text': texts[k], 'format': 'xyxy', 'scores': sc}
+            info = {'boxes': boxes[i], 'rows': rows_i, 'text': ' \n'.join(texts[k] for k in sel), 'format': 'xyxy',
+                    'scores': sc}
             ocr_results.append(info)
             if box_callback is not None:
                 box_callback(info, image=image)

@@ -58,7 +58,7 @@ def test_base_ocr_infer_and_ocr_function(models):
     east, crnn, ep, cp = models
     images, maps, _ = synth.make_pages(32, 1, 256, 384, 20)
     boxes = east.decode_output(maps[0], inputs=np.zeros((1, 256, 384, 3), np.float32))
-    res = crnn.infer({'image': images[0], 'boxes': boxes})
+    res = crnn.infer({'image': images[0], 'boxes': boxes}, combine=False, method='greedy')
     assert set(res) == {'filename', 'boxes', 'ocr', 'image'}
     index, texts, scores = opipe.recognise_rows(images[0], boxes['boxes'], cp, octc.CharTokenizer(ENGLISH_G2_CHARACTERS))
     assert len(res['ocr']) == len(index) >= 10
@@ -76,10 +76,26 @@ def test_base_ocr_infer_and_ocr_function(models):
     # the public function: detector by name, random-weight detection -> just the structure
     out = ocr(images[0], model='crnn_en', detector='east')
     assert isinstance(out, list) and len(out) == 1 and 'ocr' in out[0]
+    # reference defaults: words grouped into lines / paragraphs, beam search; on these well separated
+    # logits-free checks only the structure and the grouping are compared
+    from ocr_amd.utils.combination import combine_boxes
+    full = crnn.infer({'image': images[0], 'boxes': boxes})
+    cb, _, rows = combine_boxes(boxes['boxes'])
+    assert len(full['ocr']) == len(cb)
+    for r, bx, rw in zip(full['ocr'], cb, rows):
+        np.testing.assert_array_equal(r['boxes'], bx)
+        assert r['rows'].shape == np.asarray(rw).shape and r['text'].count(' \n') == len(rw) - 1
+    # beam search: same rows as greedy, scores are log-probabilities / length (random weights give nearly
+    # flat distributions, so the strings themselves are not comparable with greedy here; the search is
+    # checked exhaustively in tests/test_ctc_beam_cpu.py)
+    g = crnn.infer({'image': images[0], 'boxes': boxes}, combine=False, method='greedy')
+    bsr = crnn.infer({'image': images[0], 'boxes': boxes}, combine=False, method='beam_search')
+    assert len(g['ocr']) == len(bsr['ocr'])
+    for x, y in zip(g['ocr'], bsr['ocr']):
+        np.testing.assert_array_equal(x['boxes'], y['boxes'])
+    assert all(-10 < float(r['scores'][0]) <= 0 for r in bsr['ocr'])
     with pytest.raises(NotImplementedError):
-        crnn.infer(images[0], combine=True)
-    with pytest.raises(NotImplementedError):
-        crnn.infer({'image': images[0], 'boxes': boxes}, method='beam_search')
+        crnn.infer({'image': images[0], 'boxes': boxes}, dezoom_factor=2.)
 
 
 def test_runtime_object_and_nms_dispatch(models):
