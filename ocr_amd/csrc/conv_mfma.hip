@@ -13,8 +13,9 @@
 // result is a float32 fma chain: no reduced-precision step anywhere.
 //
 // Tiling (one workgroup = 4 waves = 256 threads):
-//   M: a spatial tile of 8 rows x 32 columns of output pixels (KS = 3, 2) or 256 consecutive rows
-//      of the flat (B*H*W, Cin) matrix (KS = 1); each wave owns 2 x 32 pixels,
+//   M: a spatial tile of 8 rows x 32 columns of output pixels (KS = 3, 2; three smaller shapes exist
+//      for small maps, see Geo) or 256 consecutive rows of the flat (B*H*W, Cin) matrix (KS = 1);
+//      each wave owns 2 x 32 pixels,
 //   N: NT x 32 output channels,
 //   K: chunks of CK input channels; per chunk the input tile with its halo ((8+KS-1) x (32+KS-1)
 //      pixels) and the weight slab (KS*KS x CK x N) are staged in LDS once and reused by all taps.
@@ -45,22 +46,30 @@ struct ConvArgs {
     int relu;
     float up_ry, up_rx;    // (Hs-1)/(H-1), (Ws-1)/(W-1)
     int tiles_x;
+    int n_blocks_n;        // output-channel blocks; blockIdx.x = tile * n_blocks_n + channel block
 };
 
-template <int KS>
+// Spatial tile of a workgroup: TW = 32 or 16 columns; an MFMA M tile (32 pixels) is 1 row x 32 or
+// 2 rows x 16; every wave owns MT (2 or 1) M tiles stacked vertically, the 4 waves are stacked too:
+// TH = 4 * MT * (32 / TW) rows.  (32,2) = 8 x 32 is the default; the others keep small feature maps
+// (recogniser: 16, 8 or 4 rows, widths that are odd multiples of 16) from wasting half-empty tiles.
+template <int KS, int TWc, int MT>
 struct Geo {
     static constexpr int CK = (KS == 1) ? 32 : 16;
     static constexpr int TAPS = KS * KS;
-    static constexpr int TH = 8, TW = 32;
+    static constexpr int TW = TWc, RM = 32 / TWc, TH = 4 * MT * RM;
     static constexpr int HT = TH + KS - 1, WT = TW + KS - 1;
     static constexpr int NPIX = (KS == 1) ? 256 : HT * WT;
     static constexpr int PS = CK + 4;
     static constexpr int PAD = (KS == 3) ? 1 : 0;
 };
 
-template <int KS, int NT, int POOL, bool UPCAT>
+template <int KS, int NT, int POOL, bool UPCAT, int TWc = 32, int MT = 2>
 __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a) {
-    using G = Geo<KS>;
+    using G = Geo<KS, TWc, MT>;
+    constexpr int RM = G::RM;
+    static_assert(KS != 1 || (TWc == 32 && MT == 2), "the flat GEMM uses the default tile");
+    static_assert(POOL == 0 || TWc == 16 || MT == 2, "pooling needs both rows of a 2x2 window in one wave");
     constexpr int CK = G::CK, TAPS = G::TAPS, WT = G::WT, NPIX = G::NPIX, PS = G::PS, PAD = G::PAD;
     constexpr int BN = NT * 32;
     constexpr int A_FLOATS = NPIX * PS;
@@ -73,25 +82,28 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
 
-    const int nb = blockIdx.y;
+    // the channel blocks of one spatial tile are neighbours in launch order: they read the same input
+    // tile at about the same time, so it is fetched from HBM once and served from cache to the others
+    const int nb = blockIdx.x % a.n_blocks_n;
+    const int tile = blockIdx.x / a.n_blocks_n;
     const int nK = a.cin / CK;
 
     // tile origin
     int b = 0, y0 = 0, x0 = 0;
     int64_t m0 = 0;
     if (KS == 1) {
-        m0 = (int64_t)blockIdx.x * 256;
+        m0 = (int64_t)tile * 256;
     } else {
         b = blockIdx.z;
-        y0 = (blockIdx.x / a.tiles_x) * G::TH;
-        x0 = (blockIdx.x % a.tiles_x) * G::TW;
+        y0 = (tile / a.tiles_x) * G::TH;
+        x0 = (tile % a.tiles_x) * G::TW;
     }
     const int64_t M = (int64_t)a.B * a.H * a.W;
     const int cin_x = a.cin - a.up_c;      // channels that come from a.x
 
-    floatx16 acc[2][NT];
+    floatx16 acc[MT][NT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < MT; ++r)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -190,14 +202,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
             const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
             for (int q = 0; q < CK / 8; ++q) {
-                float av[2][4], bv[NT][4];
+                float av[MT][4], bv[NT][4];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
+                for (int r = 0; r < MT; ++r) {
                     int px;
                     if (KS == 1)
                         px = wave * 64 + r * 32 + li;
                     else
-                        px = (wave * 2 + r + ky) * WT + (li + kx);
+                        px = ((wave * MT + r) * RM + li / TWc + ky) * WT + (li % TWc + kx);
                     const float4 t4 = *reinterpret_cast<const float4*>(&As[px * PS + q * 8 + lh * 4]);
                     av[r][0] = t4.x; av[r][1] = t4.y; av[r][2] = t4.z; av[r][3] = t4.w;
                 }
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int r = 0; r < 2; ++r)
+                    for (int r = 0; r < MT; ++r)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[r][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r][t], bv[nt][t], acc[r][nt], 0, 0, 0);
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
         const float bias = a.bias[co];          // bias is padded to cout_pad
         if (KS == 1) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < MT; ++r)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int64_t m = m0 + wave * 64 + r * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
@@ -243,46 +255,97 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
                 }
         } else {
             const int Hc = a.H - (KS - 1) + 2 * PAD, Wc = a.W - (KS - 1) + 2 * PAD;   // conv output size
+            // accumulator register v of a lane is pixel m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5) of its M tile,
+            // i.e. row m / TW, column m % TW of the tile rows [(wave * MT + r) * RM, +RM)
             if (POOL == 0) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int yy = y0 + wave * 2 + r;
+                for (int r = 0; r < MT; ++r) {
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
-                        const int xx = x0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                        const int m = (v & 3) + 8 * (v >> 2) + 4 * lh;
+                        const int yy = y0 + (wave * MT + r) * RM + m / TWc, xx = x0 + m % TWc;
                         float o = acc[r][nt][v] + bias;
                         if (a.relu) o = fmaxf(o, 0.0f);
                         if (co_ok && yy < Hc && xx < Wc) a.y[(((int64_t)b * Hc + yy) * Wc + xx) * a.cout + co] = o;
                     }
                 }
-            } else if (POOL == 1) {
+            } else if (TWc == 32) {
+                // rows 2w and 2w+1 are the two M tiles of this wave; column pairs are adjacent registers
                 const int Hp = Hc / 2, Wp = Wc / 2;
                 const int yy = (y0 >> 1) + wave;
+                if (POOL == 1) {
 #pragma unroll
-                for (int v = 0; v < 16; v += 2) {
-                    const int xx = (x0 >> 1) + (((v & 3) + 8 * (v >> 2) + 4 * lh) >> 1);
-                    float o = fmaxf(fmaxf(acc[0][nt][v], acc[0][nt][v + 1]), fmaxf(acc[1][nt][v], acc[1][nt][v + 1])) + bias;
-                    if (a.relu) o = fmaxf(o, 0.0f);
-                    if (co_ok && yy < Hp && xx < Wp) a.y[(((int64_t)b * Hp + yy) * Wp + xx) * a.cout + co] = o;
+                    for (int v = 0; v < 16; v += 2) {
+                        const int xx = (x0 >> 1) + (((v & 3) + 8 * (v >> 2) + 4 * lh) >> 1);
+                        float o = fmaxf(fmaxf(acc[0][nt][v], acc[0][nt][v + 1]), fmaxf(acc[MT - 1][nt][v], acc[MT - 1][nt][v + 1])) + bias;
+                        if (a.relu) o = fmaxf(o, 0.0f);
+                        if (co_ok && yy < Hp && xx < Wp) a.y[(((int64_t)b * Hp + yy) * Wp + xx) * a.cout + co] = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int xx = x0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                        float o = fmaxf(acc[0][nt][v], acc[MT - 1][nt][v]) + bias;
+                        if (a.relu) o = fmaxf(o, 0.0f);
+                        if (co_ok && yy < Hp && xx < Wc) a.y[(((int64_t)b * Hp + yy) * Wc + xx) * a.cout + co] = o;
+                    }
                 }
             } else {
-                const int Hp = Hc / 2;
-                const int yy = (y0 >> 1) + wave;
+                // TW = 16: an M tile holds two rows of 16 pixels; pixel m and m + 16 are registers v and v + 8
+                const int Hp = Hc / 2, Wp = Wc / 2;
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int xx = x0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-                    float o = fmaxf(acc[0][nt][v], acc[1][nt][v]) + bias;
-                    if (a.relu) o = fmaxf(o, 0.0f);
-                    if (co_ok && yy < Hp && xx < Wc) a.y[(((int64_t)b * Hp + yy) * Wc + xx) * a.cout + co] = o;
+                for (int r = 0; r < MT; ++r) {
+                    const int yy = (y0 >> 1) + wave * MT + r;
+                    if (POOL == 1) {
+#pragma unroll
+                        for (int v = 0; v < 8; v += 2) {
+                            const int m = (v & 3) + 8 * (v >> 2) + 4 * lh;
+                            const int xx = (x0 >> 1) + (m >> 1);
+                            float o = fmaxf(fmaxf(acc[r][nt][v], acc[r][nt][v + 1]), fmaxf(acc[r][nt][v + 8], acc[r][nt][v + 9])) + bias;
+                            if (a.relu) o = fmaxf(o, 0.0f);
+                            if (co_ok && yy < Hp && xx < Wp) a.y[(((int64_t)b * Hp + yy) * Wp + xx) * a.cout + co] = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            const int xx = x0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                            float o = fmaxf(acc[r][nt][v], acc[r][nt][v + 8]) + bias;
+                            if (a.relu) o = fmaxf(o, 0.0f);
+                            if (co_ok && yy < Hp && xx < Wc) a.y[(((int64_t)b * Hp + yy) * Wc + xx) * a.cout + co] = o;
+                        }
+                    }
                 }
             }
         }
     }
 }
 
-template <int KS, int NT, int POOL, bool UPCAT>
+template <int KS, int NT, int POOL, bool UPCAT, int TWc = 32, int MT = 2>
 void launch_variant(const ConvArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, NT, POOL, UPCAT>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, NT, POOL, UPCAT, TWc, MT>), grid, dim3(256), 0, s, a);
+}
+
+// Tile shapes built for a (kernel size, N tile, pool) combination, and the choice among them: the best
+// fill of the output map, with a penalty for the shapes that re-stage the weight slab for half the work.
+struct TileShape { int tw, mt; };
+inline int tile_rows(TileShape t) { return 4 * t.mt * (32 / t.tw); }
+
+TileShape pick_tile(int ks, int NT, int pool, int Hc, int Wc) {
+    static const TileShape all[4] = {{32, 2}, {16, 2}, {16, 1}, {32, 1}};
+    TileShape best = all[0];
+    double best_score = -1.0;
+    for (const TileShape t : all) {
+        if (NT != 2 && !(t.tw == 32 && t.mt == 2)) continue;            // only built for the 64-channel N tile
+        if (pool != 0 && t.tw == 32 && t.mt == 1) continue;
+        if (ks == 2 && t.tw == 16 && t.mt == 2) continue;
+        const int th = tile_rows(t);
+        const double covered = (double)((Hc + th - 1) / th * th) * ((Wc + t.tw - 1) / t.tw * t.tw);
+        double score = (double)Hc * Wc / covered;
+        if (t.mt == 1) score *= 0.85;
+        if (t.tw == 16) score *= 0.97;
+        if (score > best_score) { best_score = score; best = t; }
+    }
+    return best;
 }
 
 }  // namespace
@@ -332,8 +395,9 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
     ConvArgs a;
     a.x = x; a.w = L.w_f32.as<float>(); a.bias = L.bias.as<float>(); a.y = y; a.up = up_src;
     a.B = B; a.H = H; a.W = W; a.cin = L.cin; a.cout = L.cout; a.up_c = up_src ? up_c : 0; a.relu = relu ? 1 : 0;
-    a.up_ry = 0.f; a.up_rx = 0.f; a.tiles_x = 1;
+    a.up_ry = 0.f; a.up_rx = 0.f; a.tiles_x = 1; a.n_blocks_n = 1;
     dim3 grid;
+    TileShape shape{32, 2};
     if (ks == 1) {
         OCR_REQUIRE(pool == 0, "conv_mfma: 1x1 layers have no fused pool");
         if (up_src) {
@@ -345,17 +409,21 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
         const int64_t M = (int64_t)B * H * W;
         const int64_t mt = (M + 255) / 256;
         OCR_REQUIRE(mt < (1ll << 31), "conv_mfma: too many rows");
-        grid = dim3((unsigned)mt, L.cout_pad / BN, 1);
+        a.n_blocks_n = L.cout_pad / BN;
+        OCR_REQUIRE(mt * a.n_blocks_n < (1ll << 31), "conv_mfma: too many workgroups");
+        grid = dim3((unsigned)(mt * a.n_blocks_n), 1, 1);
     } else {
         OCR_REQUIRE(!up_src, "conv_mfma: upsample-concat is only fused into 1x1 layers");
         const int pad = (ks == 3) ? 1 : 0;
         const int Hc = H - (ks - 1) + 2 * pad, Wc = W - (ks - 1) + 2 * pad;
         OCR_REQUIRE(Hc > 0 && Wc > 0, "conv_mfma: input %dx%d too small for a %dx%d kernel", H, W, ks, ks);
         if (pool) OCR_REQUIRE(Hc % 2 == 0 && (pool == 2 || Wc % 2 == 0), "conv_mfma: pooled layer needs even size, got %dx%d", Hc, Wc);
-        a.tiles_x = (Wc + 31) / 32;
-        const int tiles_y = (Hc + 7) / 8;
+        shape = pick_tile(ks, NT, pool, Hc, Wc);
+        a.tiles_x = (Wc + shape.tw - 1) / shape.tw;
+        const int tiles_y = (Hc + tile_rows(shape) - 1) / tile_rows(shape);
         OCR_REQUIRE(B <= 65535, "conv_mfma: batch %d too large for one launch", B);
-        grid = dim3((unsigned)(a.tiles_x * tiles_y), L.cout_pad / BN, B);
+        a.n_blocks_n = L.cout_pad / BN;
+        grid = dim3((unsigned)(a.tiles_x * tiles_y * a.n_blocks_n), 1, B);
     }
 
     char pname[64];
@@ -373,21 +441,31 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
     ProfScope prof(pname, 2.0 * ks * ks * L.cin * L.cout * out_px,
                    4.0 * (in_elems + out_elems + (double)ks * ks * L.cin * L.cout), s);
 
-#define OCR_CONV_CASE(KS_, NT_, POOL_, UP_)                                  \
-    if (ks == KS_ && NT == NT_ && pool == POOL_ && (up_src != nullptr) == UP_) { \
-        launch_variant<KS_, NT_, POOL_, UP_>(a, grid, s);                     \
-        OCR_HIP_CHECK(hipGetLastError());                                     \
-        return OCRHIP_OK;                                                     \
+#define OCR_CONV_CASE(KS_, NT_, POOL_, UP_, TW_, MT_)                                            \
+    if (ks == KS_ && NT == NT_ && pool == POOL_ && (up_src != nullptr) == UP_ && shape.tw == TW_ && \
+        shape.mt == MT_) {                                                                          \
+        launch_variant<KS_, NT_, POOL_, UP_, TW_, MT_>(a, grid, s);                                  \
+        OCR_HIP_CHECK(hipGetLastError());                                                           \
+        return OCRHIP_OK;                                                                           \
     }
-    OCR_CONV_CASE(3, 2, 0, false)
-    OCR_CONV_CASE(3, 2, 1, false)
-    OCR_CONV_CASE(3, 2, 2, false)
-    OCR_CONV_CASE(3, 1, 0, false)
-    OCR_CONV_CASE(2, 2, 0, false)
-    OCR_CONV_CASE(1, 2, 0, false)
-    OCR_CONV_CASE(1, 1, 0, false)
-    OCR_CONV_CASE(1, 2, 0, true)
-    OCR_CONV_CASE(1, 1, 0, true)
+    OCR_CONV_CASE(3, 2, 0, false, 32, 2)
+    OCR_CONV_CASE(3, 2, 0, false, 16, 2)
+    OCR_CONV_CASE(3, 2, 0, false, 16, 1)
+    OCR_CONV_CASE(3, 2, 0, false, 32, 1)
+    OCR_CONV_CASE(3, 2, 1, false, 32, 2)
+    OCR_CONV_CASE(3, 2, 1, false, 16, 2)
+    OCR_CONV_CASE(3, 2, 1, false, 16, 1)
+    OCR_CONV_CASE(3, 2, 2, false, 32, 2)
+    OCR_CONV_CASE(3, 2, 2, false, 16, 2)
+    OCR_CONV_CASE(3, 2, 2, false, 16, 1)
+    OCR_CONV_CASE(3, 1, 0, false, 32, 2)
+    OCR_CONV_CASE(2, 2, 0, false, 32, 2)
+    OCR_CONV_CASE(2, 2, 0, false, 32, 1)
+    OCR_CONV_CASE(2, 2, 0, false, 16, 1)
+    OCR_CONV_CASE(1, 2, 0, false, 32, 2)
+    OCR_CONV_CASE(1, 1, 0, false, 32, 2)
+    OCR_CONV_CASE(1, 2, 0, true, 32, 2)
+    OCR_CONV_CASE(1, 1, 0, true, 32, 2)
 #undef OCR_CONV_CASE
     set_error("conv_mfma: no kernel variant for ks=%d NT=%d pool=%d upcat=%d", ks, NT, pool, (int)(up_src != nullptr));
     return OCRHIP_EINVAL;
