@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--words', type=int, default=220)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-pages', type=int, default=1)
+    ap.add_argument('--cpu-pages', type=int, default=4)
     return ap.parse_args()
 
 
@@ -63,6 +63,16 @@ def cpu_baseline(images, maps, east_params, crnn_params, n_pages):
             'sample': '%d page(s) %dx%d of the GPU workload through oracle/pipeline.py: batch-1 EAST (torch-CPU f32), '
                       'NumPy decode, C LANMS (1 thread), one CRNN forward per text row; %.1f s'
                       % (n_pages, images.shape[1], images.shape[2], dt)}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed counter passes of this same command
+    (tools/pmc_traffic.py over `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`), or None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+            return json.load(fh)['kernels'][kernel]['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -133,7 +143,9 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'launches': dom['launches'],
                          'avg_ms': dom['total_ms'] / dom['launches'], 'achieved': achieved,
                          'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-                         'traffic': None},
+                         'traffic': pmc_traffic(dom['name']),
+                         'algorithmic_bytes': dom['bytes'] / dom['launches'],
+                         'flop_per_launch': dom['flops'] / dom['launches']},
             'gpu_time': {'kernels_ms_per_step': gpu_ms / args.steps, 'all_mfma_conv_tflops': conv_tflops,
                          'stages_ms_per_step': {s['name']: round(s['total_ms'] / args.steps, 3) for s in stats}},
         }

@@ -45,8 +45,8 @@ struct ConvArgs {
     int up_c;
     int relu;
     float up_ry, up_rx;    // (Hs-1)/(H-1), (Ws-1)/(W-1)
-    int tiles_x;
-    int n_blocks_n;        // output-channel blocks; blockIdx.x = tile * n_blocks_n + channel block
+    int tiles_x, tiles_per_image;
+    int n_blocks_n;        // output-channel blocks; work index = (image * tiles_per_image + tile) * n_blocks_n + channel block
 };
 
 // Spatial tile of a workgroup: TW = 32 or 16 columns; an MFMA M tile (32 pixels) is 1 row x 32 or
@@ -82,19 +82,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
 
-    // the channel blocks of one spatial tile are neighbours in launch order: they read the same input
-    // tile at about the same time, so it is fetched from HBM once and served from cache to the others
-    const int nb = blockIdx.x % a.n_blocks_n;
-    const int tile = blockIdx.x / a.n_blocks_n;
+    // Workgroups are handed to the 8 XCDs (each with its own L2) round-robin in launch order.  The work
+    // index is permuted so that every XCD walks one contiguous range of it: the channel blocks of a
+    // spatial tile, and the tiles next to it, then run on the same XCD at about the same time, and the
+    // input tile (with its halo) is fetched from HBM once instead of once per channel block.
+    const unsigned total = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned work = xcd * (total >> 3) + min(xcd, total & 7u) + slot;
+    const int nb = (int)(work % (unsigned)a.n_blocks_n);
+    const int tile_all = (int)(work / (unsigned)a.n_blocks_n);
     const int nK = a.cin / CK;
 
     // tile origin
     int b = 0, y0 = 0, x0 = 0;
     int64_t m0 = 0;
     if (KS == 1) {
-        m0 = (int64_t)tile * 256;
+        m0 = (int64_t)tile_all * 256;
     } else {
-        b = blockIdx.z;
+        b = tile_all / a.tiles_per_image;
+        const int tile = tile_all % a.tiles_per_image;
         y0 = (tile / a.tiles_x) * G::TH;
         x0 = (tile % a.tiles_x) * G::TW;
     }
@@ -395,7 +400,7 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
     ConvArgs a;
     a.x = x; a.w = L.w_f32.as<float>(); a.bias = L.bias.as<float>(); a.y = y; a.up = up_src;
     a.B = B; a.H = H; a.W = W; a.cin = L.cin; a.cout = L.cout; a.up_c = up_src ? up_c : 0; a.relu = relu ? 1 : 0;
-    a.up_ry = 0.f; a.up_rx = 0.f; a.tiles_x = 1; a.n_blocks_n = 1;
+    a.up_ry = 0.f; a.up_rx = 0.f; a.tiles_x = 1; a.tiles_per_image = 1; a.n_blocks_n = 1;
     dim3 grid;
     TileShape shape{32, 2};
     if (ks == 1) {
@@ -421,13 +426,16 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
         shape = pick_tile(ks, NT, pool, Hc, Wc);
         a.tiles_x = (Wc + shape.tw - 1) / shape.tw;
         const int tiles_y = (Hc + tile_rows(shape) - 1) / tile_rows(shape);
-        OCR_REQUIRE(B <= 65535, "conv_mfma: batch %d too large for one launch", B);
+        a.tiles_per_image = a.tiles_x * tiles_y;
         a.n_blocks_n = L.cout_pad / BN;
-        grid = dim3((unsigned)(a.tiles_x * tiles_y * a.n_blocks_n), 1, B);
+        const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
+        OCR_REQUIRE(wgs < (1ll << 31), "conv_mfma: too many workgroups");
+        grid = dim3((unsigned)wgs, 1, 1);
     }
 
     char pname[64];
-    std::snprintf(pname, sizeof(pname), "conv_mfma_f32<ks%d,n%d,pool%d,up%d>", ks, BN, pool, (int)(up_src != nullptr));
+    std::snprintf(pname, sizeof(pname), "conv_mfma_f32<ks%d,n%d,pool%d,up%d,tile%dx%d>", ks, BN, pool, (int)(up_src != nullptr),
+                  ks == 1 ? 256 : tile_rows(shape), ks == 1 ? 1 : shape.tw);
     double out_px, in_elems;
     if (ks == 1) {
         out_px = (double)B * H * W;

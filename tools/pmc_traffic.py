@@ -1,0 +1,57 @@
+"""Turn the FETCH_SIZE and WRITE_SIZE passes of `rocprofv3 --pmc` over bench.py into per-kernel HBM traffic.
+
+    python tools/pmc_traffic.py <fetch dir> <write dir> > profiles/pmc_traffic.json
+
+Kernel names are folded to the stage names bench.py reports (one name per convolution variant and tile shape).  traffic = 2 x FETCH_SIZE + WRITE_SIZE per launch: on gfx950 FETCH_SIZE tallies the 128-byte
+reads of 16-byte-per-lane loads at 64 bytes, WRITE_SIZE is exact for 16-byte-per-lane and dword stores.
+Both counters are reported in KiB.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def stage_name(kernel):
+    m = re.search(r'conv_mfma_f32_kernel<(\d+), (\d+), (\d+), (true|false), (\d+), (\d+)>', kernel)
+    if m:
+        ks, tw, mt = int(m.group(1)), int(m.group(5)), int(m.group(6))
+        rows, cols = (256, 1) if ks == 1 else (4 * mt * (32 // tw), tw)
+        return 'conv_mfma_f32<ks%d,n%d,pool%s,up%d,tile%dx%d>' % (ks, 32 * int(m.group(2)), m.group(3),
+                                                                  m.group(4) == 'true', rows, cols)
+    m = re.search(r'(\w+)_kernel', kernel)
+    if m:
+        return m.group(1)
+    return kernel.split('(anonymous namespace)::')[-1].split('(')[0].replace('void ', '')
+
+
+def totals(d):
+    acc = defaultdict(lambda: [0, 0.0])
+    for path in glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True):
+        with open(path, newline='') as fh:
+            for row in csv.DictReader(fh):
+                a = acc[stage_name(row['Kernel_Name'])]
+                a[0] += 1
+                a[1] += float(row['Counter_Value'])
+    return acc
+
+
+def main(fetch_dir, write_dir):
+    f, w = totals(fetch_dir), totals(write_dir)
+    out = {}
+    for k in sorted(set(f) & set(w)):
+        if f[k][0] != w[k][0]:
+            continue                      # the two passes must have seen the same launches
+        n = f[k][0]
+        fetch, write = f[k][1] / n * 1024.0, w[k][1] / n * 1024.0
+        out[k] = {'launches': n, 'fetch_size_bytes_per_launch': fetch, 'write_size_bytes_per_launch': write,
+                  'traffic_bytes_per_launch': 2.0 * fetch + write}
+    json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1',
+               'correction': 'traffic = 2 x FETCH_SIZE + WRITE_SIZE', 'kernels': out}, sys.stdout, indent=1)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])
