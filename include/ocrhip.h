@@ -150,25 +150,35 @@ int ocrhip_crop_resize_pack(ocrhip_handle h, const uint8_t* d_img, int B, int H,
  *   FeatureExtraction.ConvNet.{12,15}.{weight,bias,running_mean,running_var},
  *   SequenceModeling.{0,1}.rnn.{weight_ih_l0,weight_hh_l0,bias_ih_l0,bias_hh_l0}[_reverse],
  *   SequenceModeling.{0,1}.linear.{weight,bias}, Prediction.{weight,bias}
- * The vocabulary size is the row count of Prediction.weight. */
+ * The vocabulary size is the row count of Prediction.weight.
+ * ResNet extractor (crnn_arch.py:330-425, `backbone='resnet'`): chosen when FeatureExtraction.ConvNet.conv0_1.weight
+ * is present; tensors conv0_{1,2}, bn0_{1,2}, layer{1..4}.{b}.{conv1,bn1,conv2,bn2}, layer{1,2,3}.0.downsample.{0,1},
+ * conv{1,2,3}, bn{1,2,3}, conv4_{1,2}, bn4_{1,2} under FeatureExtraction.ConvNet (EasyOCR's ResNet_FeatureExtractor
+ * keys).  It yields 512 features per step, so SequenceModeling.0.rnn.weight_ih_l0* is (1024, 512).  As in the
+ * reference graph, only the first block of layer1-3 has a skip connection and the block batch-norms use eps 1e-3. */
 int ocrhip_crnn_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n);
 
 /* CRNN forward + optional fused CTC greedy.  Replaces `compiled_infer(inp[None])` per text row in
  * BaseOCR.infer (models/ocr/base_ocr.py:171-201) for a whole batch of equal-width crops, and (when
  * d_tokens != NULL) pad_batch + ctc_decode (base_ocr.py:209-222, utils/text/ctc_decoder.py:14-35).
  *   d_crops : device (n,64,Wpad,1) float32 normalised crops (ocrhip_crop_resize_pack output)
- *   d_logits: device (n,T,V) float32 raw logits, T = Wpad/4 - 1, or NULL
+ *   d_logits: device (n,T,V) float32 raw logits, T = ocrhip_crnn_seq_len(h, Wpad), or NULL
  *   d_tokens: device (n,T) int32 greedy tokens padded with -1, or NULL
  *   d_scores: device (n) float32 -sum_t max_v logit / T, or NULL (required with d_tokens) */
 int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, int compute_dtype,
                         float* d_logits, int* d_tokens, float* d_scores, ocrhip_stream stream);
 int ocrhip_crnn_vocab_size(ocrhip_handle h);
 
+/* Time steps the loaded recogniser produces for a crop of padded width wpad: wpad/4 - 1 with the VGG
+ * extractor (3 valid columns lost by its last 2x2 convolution, crnn_arch.py:38-41), wpad/4 + 1 with the
+ * ResNet extractor (crnn_arch.py:389-423).  0 when no weights are loaded. */
+int ocrhip_crnn_seq_len(ocrhip_handle h, int wpad);
+
 /* CRNN forward + CTC greedy for a whole batch of crops of DIFFERENT widths in one call: what
  * BaseOCR.infer does for all the rows of an image (one forward per row, pad_batch of the logits,
  * ctc_decode with lengths; models/ocr/base_ocr.py:171-222, utils/sequence_utils.py:16-62).  The
  * feature extractor runs once per group of equal width; the recurrent layers, the Dense layers and
- * the CTC decoding run once over all sequences (ragged: sequence i has T_i = out_w[i]/4 - 1 steps).
+ * the CTC decoding run once over all sequences (ragged: sequence i has T_i = ocrhip_crnn_seq_len(h, out_w[i]) steps).
  *   d_packed : device, crop i is a (64, out_w[i]) float32 plane; planes back to back in crop order
  *              (the layout ocrhip_crop_resize_pack writes for cumulative dst offsets)
  *   out_w    : HOST (n) int32 padded widths, non-decreasing

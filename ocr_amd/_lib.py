@@ -43,6 +43,7 @@ SIGNATURES = {
     'ocrhip_crnn_load_weights': (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_int]),
     'ocrhip_crnn_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ocrhip_crnn_vocab_size': (c_int, [c_void_p]),
+    'ocrhip_crnn_seq_len': (c_int, [c_void_p, c_int]),
     'ocrhip_crnn_forward_packed': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
     'ocrhip_crnn_get_activation': (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64)]),

@@ -150,7 +150,7 @@ int get(const Weights& W, const std::string& name, std::initializer_list<int64_t
 
 // conv (+ optional bias) followed by inference batch-norm -> folded weight / bias
 int fold_conv_bn(const Weights& W, const std::string& conv, const std::string& bn, bool has_bias, int cout, int cin,
-                 int ks, std::vector<float>& w_out, std::vector<float>& b_out) {
+                 int ks, std::vector<float>& w_out, std::vector<float>& b_out, double eps = kBnEps) {
     const float *w = nullptr, *b = nullptr;
     OCR_TRY(get(W, conv + ".weight", {cout, cin, ks, ks}, &w));
     if (has_bias) OCR_TRY(get(W, conv + ".bias", {cout}, &b));
@@ -165,7 +165,7 @@ int fold_conv_bn(const Weights& W, const std::string& conv, const std::string& b
         OCR_TRY(get(W, bn + ".running_mean", {cout}, &mean));
         OCR_TRY(get(W, bn + ".running_var", {cout}, &var));
         for (int o = 0; o < cout; ++o) {
-            const double sc = (double)g[o] / std::sqrt((double)var[o] + kBnEps);
+            const double sc = (double)g[o] / std::sqrt((double)var[o] + eps);
             for (size_t i = 0; i < per_out; ++i) w_out[(size_t)o * per_out + i] = (float)((double)w_out[(size_t)o * per_out + i] * sc);
             b_out[o] = (float)(((double)b_out[o] - (double)mean[o]) * sc + (double)beta[o]);
         }
@@ -430,24 +430,71 @@ int ocrhip_crop_resize_pack(ocrhip_handle h, const uint8_t* d_img, int B, int H,
 
 // ------------------------------------------------------------------------------------------ CRNN
 
+// ResNet extractor as the reference builds it (architectures/crnn_arch.py:330-425): layers in execution order.
+// The batch-norms inside the BasicBlocks (and after their 1x1 downsample) use the Conv2DBN default epsilon
+// 1e-3 (current_blocks.py:222), the stage convolutions pass 1e-5 (crnn_arch.py:416).
+struct ResLayer { std::string conv, bn; int cin, cout, ks; double eps; };
+
+static std::vector<ResLayer> resnet_layers() {
+    const std::string pre = "FeatureExtraction.ConvNet.";
+    std::vector<ResLayer> L;
+    L.push_back({pre + "conv0_1", pre + "bn0_1", 1, 32, 3, 1e-5});
+    L.push_back({pre + "conv0_2", pre + "bn0_2", 32, 64, 3, 1e-5});
+    const int blocks[4] = {1, 2, 5, 3}, chans[4] = {128, 256, 512, 512};
+    int cin = 64;
+    for (int st = 0; st < 4; ++st) {
+        const std::string lay = pre + "layer" + std::to_string(st + 1) + ".";
+        const int c = chans[st];
+        if (cin != c) L.push_back({lay + "0.downsample.0", lay + "0.downsample.1", cin, c, 1, 1e-3});
+        for (int b = 0; b < blocks[st]; ++b) {
+            const std::string blk = lay + std::to_string(b) + ".";
+            L.push_back({blk + "conv1", blk + "bn1", b == 0 ? cin : c, c, 3, 1e-3});
+            L.push_back({blk + "conv2", blk + "bn2", c, c, 3, 1e-3});
+        }
+        if (st < 3) {
+            const std::string k = std::to_string(st + 1);
+            L.push_back({pre + "conv" + k, pre + "bn" + k, c, c, 3, 1e-5});
+        }
+        cin = c;
+    }
+    L.push_back({pre + "conv4_1", pre + "bn4_1", 512, 512, 2, 1e-5});
+    L.push_back({pre + "conv4_2", pre + "bn4_2", 512, 512, 2, 1e-5});
+    return L;
+}
+
 int ocrhip_crnn_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n) {
     OCR_HANDLE(h);
     OCR_REQUIRE(w && n > 0, "crnn_load_weights: no tensors");
     Weights W{w, n};
     CrnnNet& net = h->crnn;
     net.loaded = false;
-    // (Sequential index, cin, cout, kernel, bias, batch-norm index or -1), crnn_arch.py:38-41
-    const int cfg[7][6] = {{0, 1, 32, 3, 1, -1},    {3, 32, 64, 3, 1, -1},   {6, 64, 128, 3, 1, -1}, {8, 128, 128, 3, 1, -1},
-                           {11, 128, 256, 3, 0, 12}, {14, 256, 256, 3, 0, 15}, {18, 256, 256, 2, 1, -1}};
     std::vector<float> wf, bf;
-    for (int i = 0; i < 7; ++i) {
-        const std::string conv = "FeatureExtraction.ConvNet." + std::to_string(cfg[i][0]);
-        const std::string bn = cfg[i][5] >= 0 ? "FeatureExtraction.ConvNet." + std::to_string(cfg[i][5]) : std::string();
-        OCR_TRY(fold_conv_bn(W, conv, bn, cfg[i][4] != 0, cfg[i][2], cfg[i][1], cfg[i][3], wf, bf));
-        if (i == 0)
-            OCR_TRY(prepare_conv_direct(net.conv[i], wf.data(), bf.data(), cfg[i][2], cfg[i][1], cfg[i][3]));
-        else
-            OCR_TRY(prepare_conv_mfma(net.conv[i], wf.data(), bf.data(), cfg[i][2], cfg[i][1], cfg[i][3]));
+    net.backbone = W.find("FeatureExtraction.ConvNet.conv0_1.weight") ? 1 : 0;
+    net.feat_c = net.backbone ? 512 : 256;
+    if (net.backbone) {
+        const std::vector<ResLayer> layers = resnet_layers();
+        OCR_REQUIRE(layers.size() == 32, "crnn_load_weights: internal layer table");
+        for (size_t i = 0; i < layers.size(); ++i) {
+            const ResLayer& r = layers[i];
+            OCR_TRY(fold_conv_bn(W, r.conv, r.bn, false, r.cout, r.cin, r.ks, wf, bf, r.eps));
+            if (i == 0)
+                OCR_TRY(prepare_conv_direct(net.rconv[i], wf.data(), bf.data(), r.cout, r.cin, r.ks));
+            else
+                OCR_TRY(prepare_conv_mfma(net.rconv[i], wf.data(), bf.data(), r.cout, r.cin, r.ks));
+        }
+    } else {
+        // (Sequential index, cin, cout, kernel, bias, batch-norm index or -1), crnn_arch.py:38-41
+        const int cfg[7][6] = {{0, 1, 32, 3, 1, -1},    {3, 32, 64, 3, 1, -1},   {6, 64, 128, 3, 1, -1}, {8, 128, 128, 3, 1, -1},
+                               {11, 128, 256, 3, 0, 12}, {14, 256, 256, 3, 0, 15}, {18, 256, 256, 2, 1, -1}};
+        for (int i = 0; i < 7; ++i) {
+            const std::string conv = "FeatureExtraction.ConvNet." + std::to_string(cfg[i][0]);
+            const std::string bn = cfg[i][5] >= 0 ? "FeatureExtraction.ConvNet." + std::to_string(cfg[i][5]) : std::string();
+            OCR_TRY(fold_conv_bn(W, conv, bn, cfg[i][4] != 0, cfg[i][2], cfg[i][1], cfg[i][3], wf, bf));
+            if (i == 0)
+                OCR_TRY(prepare_conv_direct(net.conv[i], wf.data(), bf.data(), cfg[i][2], cfg[i][1], cfg[i][3]));
+            else
+                OCR_TRY(prepare_conv_mfma(net.conv[i], wf.data(), bf.data(), cfg[i][2], cfg[i][1], cfg[i][3]));
+        }
     }
     const int Hd = net.hidden;
     for (int l = 0; l < 2; ++l) {
@@ -455,13 +502,14 @@ int ocrhip_crnn_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n
         for (int d = 0; d < 2; ++d) {
             const std::string suf = d ? "_reverse" : "";
             const float *wih = nullptr, *whh = nullptr, *bih = nullptr, *bhh = nullptr;
-            OCR_TRY(get(W, pre + ".rnn.weight_ih_l0" + suf, {4 * Hd, Hd}, &wih));
+            const int in_c = l == 0 ? net.feat_c : Hd;
+            OCR_TRY(get(W, pre + ".rnn.weight_ih_l0" + suf, {4 * Hd, in_c}, &wih));
             OCR_TRY(get(W, pre + ".rnn.weight_hh_l0" + suf, {4 * Hd, Hd}, &whh));
             OCR_TRY(get(W, pre + ".rnn.bias_ih_l0" + suf, {4 * Hd}, &bih));
             OCR_TRY(get(W, pre + ".rnn.bias_hh_l0" + suf, {4 * Hd}, &bhh));
             std::vector<float> bsum(4 * Hd);
             for (int i = 0; i < 4 * Hd; ++i) bsum[i] = bih[i] + bhh[i];
-            OCR_TRY(prepare_conv_mfma(net.wih[l][d], wih, bsum.data(), 4 * Hd, Hd, 1));
+            OCR_TRY(prepare_conv_mfma(net.wih[l][d], wih, bsum.data(), 4 * Hd, in_c, 1));
             OCR_TRY(net.whh[l][d].reserve((size_t)4 * Hd * Hd * sizeof(float)));
             OCR_HIP_CHECK(hipMemcpy(net.whh[l][d].ptr, whh, (size_t)4 * Hd * Hd * sizeof(float), hipMemcpyHostToDevice));
         }
@@ -487,8 +535,63 @@ int ocrhip_crnn_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n
 
 int ocrhip_crnn_vocab_size(ocrhip_handle h) { return (h && h->crnn.loaded) ? h->crnn.vocab : 0; }
 
-// Feature extractor for a batch of equal-width crops: (n,64,Wpad,1) -> feats (n,T,256), T = Wpad/4 - 1.
+int ocrhip_crnn_seq_len(ocrhip_handle h, int wpad) { return (h && h->crnn.loaded && wpad > 0) ? h->crnn.seq_len(wpad) : 0; }
+
+// ResNet extractor: (n,64,W,1) -> feats (n,T,512), T = W/4 + 1.  Three rotating buffers: A / B ping-pong and R
+// for the 1x1 downsample that the first block of a stage adds back.  The reference adds a skip connection only
+// there (crnn_arch.py:357); the other blocks are plain conv-bn-relu-conv-bn-relu.  The two 2x2 poolings of
+// strides 2 are fused into the convolution in front of them.
+static int crnn_features_resnet(CrnnNet& net, const float* x, int n, int Wpad, float* feats, hipStream_t s) {
+    OCR_REQUIRE(Wpad % 4 == 0, "crnn: the ResNet extractor needs a width that is a multiple of 4 (got %d)", Wpad);
+    const size_t per_buf = (size_t)n * Wpad * 2048 * sizeof(float) + (size_t)n * 8 * 3 * 512 * sizeof(float);
+    for (int i = 0; i < 3; ++i) OCR_TRY(net.act[i].reserve(per_buf));
+    float* A = net.act[0].as<float>();
+    float* Bf = net.act[1].as<float>();
+    float* R = net.act[2].as<float>();
+    const ConvLayer* L = net.rconv;
+    int li = 0;
+    OCR_TRY(launch_conv_first(L[li++], x, false, A, n, 64, Wpad, 0, s));                                  // (n,64,W,32)
+    OCR_TRY(launch_conv_mfma(L[li++], A, Bf, n, 64, Wpad, 1, true, nullptr, 0, s));                      // (n,32,W/2,64)
+    float *cur = Bf, *other = A;
+    int H = 32, W = Wpad / 2;
+    const int blocks[4] = {1, 2, 5, 3}, chans[4] = {128, 256, 512, 512};
+    int cin = 64;
+    for (int st = 0; st < 4; ++st) {
+        const int c = chans[st];
+        const bool down = cin != c;
+        if (down) OCR_TRY(launch_conv_mfma(L[li++], cur, R, 1, 1, n * H * W, 0, false, nullptr, 0, s));  // 1x1, bn, no relu
+        for (int b = 0; b < blocks[st]; ++b) {
+            OCR_TRY(launch_conv_mfma(L[li++], cur, other, n, H, W, 0, true, nullptr, 0, s));
+            OCR_TRY(launch_conv_mfma(L[li++], other, cur, n, H, W, 0, true, nullptr, 0, s, (down && b == 0) ? R : nullptr));
+        }
+        if (st == 0) {                      // conv1 + max-pool 2x2
+            OCR_TRY(launch_conv_mfma(L[li++], cur, other, n, H, W, 1, true, nullptr, 0, s));
+            std::swap(cur, other); H /= 2; W /= 2;
+        } else if (st == 1) {               // conv2, then width padding + max-pool 2x2 with strides (2,1)
+            OCR_TRY(launch_conv_mfma(L[li++], cur, other, n, H, W, 0, true, nullptr, 0, s));
+            OCR_TRY(launch_pad_maxpool(other, cur, n, H, W, c, 2, 2, 2, 1, 1, s));
+            H /= 2; W += 1;
+        } else if (st == 2) {               // conv3
+            OCR_TRY(launch_conv_mfma(L[li++], cur, other, n, H, W, 0, true, nullptr, 0, s));
+            std::swap(cur, other);
+        }
+        cin = c;
+    }
+    // conv4_1: 2x2, strides (2,1), on the width-padded map.  Every pair of rows is its own 2-row image for the
+    // stride-1 kernel: (n,8,W+2,512) viewed as (4n,2,W+2,512) -> (4n,1,W+1,512) = (n,4,W+1,512).
+    OCR_REQUIRE(H == 8, "crnn: internal size error (H=%d)", H);
+    OCR_TRY(launch_pad_maxpool(cur, other, n, H, W, 512, 1, 1, 1, 1, 1, s));
+    OCR_TRY(launch_conv_mfma(L[li++], other, cur, n * 4, 2, W + 2, 0, true, nullptr, 0, s));
+    OCR_TRY(launch_conv_mfma(L[li++], cur, other, n, 4, W + 1, 0, true, nullptr, 0, s));                  // (n,3,W,512)
+    OCR_REQUIRE(li == 32 && W == net.seq_len(Wpad), "crnn: internal layer count error");
+    OCR_TRY(launch_mean_rows(other, feats, n, 3, W, 512, s));
+    return OCRHIP_OK;
+}
+
+// Feature extractor for a batch of equal-width crops: (n,64,Wpad,1) -> feats (n,T,feat_c).
+// VGG: T = Wpad/4 - 1, 256 features.
 static int crnn_features(CrnnNet& net, const float* x, int n, int Wpad, float* feats, hipStream_t s) {
+    if (net.backbone) return crnn_features_resnet(net, x, n, Wpad, feats, s);
     const int Hin = 64, Hd = net.hidden;
     const int T = Wpad / 4 - 1;
     const size_t nW = (size_t)n * Wpad;
@@ -563,15 +666,15 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
     OCR_REQUIRE(d_logits || d_tokens, "crnn_forward: ask for logits and/or tokens");
     OCR_REQUIRE(!d_tokens || d_scores, "crnn_forward: d_scores is required with d_tokens");
     hipStream_t s = (hipStream_t)stream;
-    const int Hd = net.hidden;
-    const int T = Wpad / 4 - 1;
+    const int Fc = net.feat_c;
+    const int T = net.seq_len(Wpad);
     OCR_REQUIRE(T >= 1, "crnn_forward: crop too narrow");
     const int64_t R = (int64_t)n * T;
-    OCR_TRY(net.feats.reserve((size_t)R * Hd * sizeof(float)));
+    OCR_TRY(net.feats.reserve((size_t)R * Fc * sizeof(float)));
     float* feats = net.feats.as<float>();
     net.taps.clear();
     OCR_TRY(crnn_features(net, reinterpret_cast<const float*>(d_crops), n, Wpad, feats, s));
-    record(net.taps, "features", feats, n, T, Hd, 1);
+    record(net.taps, "features", feats, n, T, Fc, 1);
     float* logits = d_logits;
     if (!logits) {
         OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));
@@ -596,13 +699,13 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
     OCR_REQUIRE(d_logits || d_tokens, "crnn_forward_packed: ask for logits and/or tokens");
     OCR_REQUIRE(!d_tokens || d_scores, "crnn_forward_packed: d_scores is required with d_tokens");
     hipStream_t s = (hipStream_t)stream;
-    const int Hd = net.hidden;
+    const int Fc = net.feat_c;
     std::vector<int> meta((size_t)2 * n);        // [T of each crop | first row of each crop]
     int64_t R = 0;
     for (int i = 0; i < n; ++i) {
         OCR_REQUIRE(out_w[i] >= 8 && out_w[i] % 4 == 0 && (i == 0 || out_w[i] >= out_w[i - 1]),
                     "crnn_forward_packed: widths must be multiples of 4, >= 8 and non-decreasing (crop %d: %d)", i, out_w[i]);
-        meta[i] = out_w[i] / 4 - 1;
+        meta[i] = net.seq_len(out_w[i]);
         meta[n + i] = (int)R;
         R += meta[i];
         OCR_REQUIRE(R < (1ll << 31), "crnn_forward_packed: too many time steps in one batch");
@@ -615,11 +718,11 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
     const int* d_row0 = d_T + n;
     if (d_lengths) OCR_HIP_CHECK(hipMemcpyAsync(d_lengths, d_T, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, s));
 
-    OCR_TRY(net.feats.reserve((size_t)R * Hd * sizeof(float)));
+    OCR_TRY(net.feats.reserve((size_t)R * Fc * sizeof(float)));
     float* feats = net.feats.as<float>();
     net.taps.clear();
     // feature extractor: one pass per group of equal width, split so that a pass stays within the workspace budget
-    const int64_t max_elems = 1ll << 20;         // n_group * Wpad per pass (act[0] = 2 GB at most)
+    const int64_t max_elems = net.backbone ? (1ll << 18) : (1ll << 20);      // n_group * Wpad per pass (2 GB per buffer at most)
     const float* x = reinterpret_cast<const float*>(d_packed);
     int64_t off = 0;
     for (int i = 0; i < n;) {
@@ -629,12 +732,12 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
         const int per_pass = (int)std::max<int64_t>(1, max_elems / w);
         for (int c0 = i; c0 < j; c0 += per_pass) {
             const int c1 = std::min(j, c0 + per_pass);
-            OCR_TRY(crnn_features(net, x + off, c1 - c0, w, feats + (size_t)meta[n + c0] * Hd, s));
+            OCR_TRY(crnn_features(net, x + off, c1 - c0, w, feats + (size_t)meta[n + c0] * Fc, s));
             off += (int64_t)(c1 - c0) * 64 * w;
         }
         i = j;
     }
-    record(net.taps, "features", feats, 1, R, Hd, 1);
+    record(net.taps, "features", feats, 1, R, Fc, 1);
     float* logits = d_logits;
     if (!logits) {
         OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));

@@ -32,6 +32,7 @@ SOURCES = {
     'conv_direct.hip': [],
     'conv_mfma.hip': [],
     'rnn.hip': [],
+    'pool.hip': [],
 }
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 'ocrhip.h')]
 

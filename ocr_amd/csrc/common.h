@@ -120,12 +120,16 @@ struct LstmDir {
 struct CrnnNet {
     bool loaded = false;
     int vocab = 0, vocab_pad = 0, hidden = 256;
-    ConvLayer conv[7];       // ConvNet.0,3,6,8,11,14,18
-    ConvLayer wih[2][2];     // [layer][dir] input projections 256 -> 1024 (bias = b_ih + b_hh)
+    int backbone = 0;        // 0: VGG extractor (256 features, T = W/4 - 1); 1: ResNet extractor (512 features, T = W/4 + 1)
+    int feat_c = 256;
+    int seq_len(int wpad) const { return wpad / 4 + (backbone ? 1 : -1); }
+    ConvLayer conv[7];       // VGG: ConvNet.0,3,6,8,11,14,18
+    ConvLayer rconv[32];     // ResNet: in execution order, see crnn_load_resnet
+    ConvLayer wih[2][2];     // [layer][dir] input projections feat_c / 256 -> 1024 (bias = b_ih + b_hh)
     DevBuf whh[2][2];        // [layer][dir] (1024,256) float32
     ConvLayer linear[2];     // 512 -> 256
     ConvLayer pred;          // 256 -> vocab
-    DevBuf act[2];
+    DevBuf act[3];
     DevBuf feats, xw, hbuf, cbuf, seq, lin, logits, meta;
     PinnedRing ring;
     std::map<std::string, Activation> taps;
@@ -152,8 +156,9 @@ namespace ocrhip {
 //   up_src != nullptr: the first up_c input channels are the x2 align-corners bilinear upsampling of
 //   up_src (B,H/2,W/2,up_c) and the remaining cin - up_c channels come from x (B,H,W,cin-up_c).
 int prepare_conv_mfma(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);
+//   residual != nullptr (unpooled ks 3 / 2 only): a tensor shaped like y, added before the ReLU.
 int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
-                     const float* up_src, int up_c, hipStream_t s);
+                     const float* up_src, int up_c, hipStream_t s, const float* residual = nullptr);
 
 // conv_direct.hip: first layers (Cin 3 or 1) and the 32->6 sigmoid heads.
 int prepare_conv_direct(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);
@@ -175,6 +180,11 @@ int launch_lanms(ocrhip_ctx* h, const float* xyxy, const float* scores, const in
 int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* rects, const int* box_img,
                             const int* inter, const int* out_w, const int64_t* dst_off, int n, int out_h,
                             void* packed, int out_dtype, hipStream_t s);
+
+// pool.hip: zero padding of the width by pad_w on both sides, then max pooling (window ph x pw, strides sh x sw,
+// no further padding).  A 1x1 window with unit strides is a plain zero-padding copy.
+int launch_pad_maxpool(const float* x, float* y, int B, int H, int W, int C, int ph, int pw, int sh, int sw, int pad_w,
+                       hipStream_t s);
 
 // rnn.hip
 int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);

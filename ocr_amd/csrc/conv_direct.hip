@@ -155,7 +155,7 @@ int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y,
     const float* w = L.w_f32.as<float>();
     const float* bias = L.bias.as<float>();
     const double px = (double)B * H * W;
-    ProfScope prof(L.cin == 3 ? "conv_first<3,64>" : "conv_first<1,32,pool>", 2.0 * 9 * L.cin * L.cout * px,
+    ProfScope prof(L.cin == 3 ? "conv_first<3,64>" : (pool ? "conv_first<1,32,pool>" : "conv_first<1,32>"), 2.0 * 9 * L.cin * L.cout * px,
                    px * L.cin * (x_is_u8 ? 1.0 : 4.0) + 4.0 * px * L.cout / (pool ? 4.0 : 1.0), s);
     if (L.cin == 3 && L.cout == 64 && pool == 0) {
         dim3 grid((W + 63) / 64, H, B), block(256);
@@ -167,6 +167,9 @@ int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y,
         OCR_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_first: pooled layer needs even H, W (got %dx%d)", H, W);
         dim3 grid((W / 2 + 63) / 64, H / 2, B), block(256);
         hipLaunchKernelGGL((conv_first_kernel<1, 32, true, false>), grid, block, 0, s, x, w, bias, y, H, W);
+    } else if (L.cin == 1 && L.cout == 32 && pool == 0 && !x_is_u8) {
+        dim3 grid((W + 63) / 64, H, B), block(256);
+        hipLaunchKernelGGL((conv_first_kernel<1, 32, false, false>), grid, block, 0, s, x, w, bias, y, H, W);
     } else {
         set_error("conv_first: unsupported configuration cin=%d cout=%d pool=%d u8=%d", L.cin, L.cout, pool, (int)x_is_u8);
         return OCRHIP_EINVAL;

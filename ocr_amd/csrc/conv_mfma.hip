@@ -40,6 +40,7 @@ struct ConvArgs {
     const float* bias;     // cout_pad
     float* y;
     const float* up;       // UPCAT: (B,H/2,W/2,up_c)
+    const float* res;      // optional residual, same shape as y, added before the ReLU (unpooled 3x3 / 2x2 layers)
     int B, H, W;           // input spatial size (KS == 1: H*W*B = M rows)
     int cin, cout;         // cin = total reduction channels (incl. upsampled ones)
     int up_c;
@@ -270,8 +271,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
                         const int m = (v & 3) + 8 * (v >> 2) + 4 * lh;
                         const int yy = y0 + (wave * MT + r) * RM + m / TWc, xx = x0 + m % TWc;
                         float o = acc[r][nt][v] + bias;
-                        if (a.relu) o = fmaxf(o, 0.0f);
-                        if (co_ok && yy < Hc && xx < Wc) a.y[(((int64_t)b * Hc + yy) * Wc + xx) * a.cout + co] = o;
+                        if (co_ok && yy < Hc && xx < Wc) {
+                            const int64_t idx = (((int64_t)b * Hc + yy) * Wc + xx) * a.cout + co;
+                            if (a.res) o += a.res[idx];
+                            if (a.relu) o = fmaxf(o, 0.0f);
+                            a.y[idx] = o;
+                        }
                     }
                 }
             } else if (TWc == 32) {
@@ -391,14 +396,15 @@ int prepare_conv_mfma(ConvLayer& L, const float* w_oihw, const float* bias, int 
 }
 
 int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
-                     const float* up_src, int up_c, hipStream_t s) {
+                     const float* up_src, int up_c, hipStream_t s, const float* residual) {
     OCR_REQUIRE(!L.direct && L.w_f32.ptr, "conv_mfma: layer not prepared");
     OCR_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "conv_mfma: bad arguments B=%d H=%d W=%d", B, H, W);
     const int ks = L.ks;
     const int BN = (L.cout_pad % 64 == 0) ? 64 : 32;
     const int NT = BN / 32;
     ConvArgs a;
-    a.x = x; a.w = L.w_f32.as<float>(); a.bias = L.bias.as<float>(); a.y = y; a.up = up_src;
+    OCR_REQUIRE(!residual || (L.ks != 1 && pool == 0), "conv_mfma: a residual goes with an unpooled spatial layer");
+    a.x = x; a.w = L.w_f32.as<float>(); a.bias = L.bias.as<float>(); a.y = y; a.up = up_src; a.res = residual;
     a.B = B; a.H = H; a.W = W; a.cin = L.cin; a.cout = L.cout; a.up_c = up_src ? up_c : 0; a.relu = relu ? 1 : 0;
     a.up_ry = 0.f; a.up_rx = 0.f; a.tiles_x = 1; a.tiles_per_image = 1; a.n_blocks_n = 1;
     dim3 grid;
@@ -447,7 +453,7 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
     }
     const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : (pool == 2 ? 2.0 : 1.0));
     ProfScope prof(pname, 2.0 * ks * ks * L.cin * L.cout * out_px,
-                   4.0 * (in_elems + out_elems + (double)ks * ks * L.cin * L.cout), s);
+                   4.0 * (in_elems + out_elems * (residual ? 2.0 : 1.0) + (double)ks * ks * L.cin * L.cout), s);
 
 #define OCR_CONV_CASE(KS_, NT_, POOL_, UP_, TW_, MT_)                                            \
     if (ks == KS_ && NT == NT_ && pool == POOL_ && (up_src != nullptr) == UP_ && shape.tw == TW_ && \

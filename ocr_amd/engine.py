@@ -185,13 +185,20 @@ class HipContext:
     def vocab_size(self):
         return int(self.lib.ocrhip_crnn_vocab_size(self._h))
 
+    def seq_len(self, wpad):
+        """Time steps of the loaded recogniser for padded crop width(s) `wpad` (VGG: w/4 - 1, ResNet: w/4 + 1)."""
+        delta = int(self.lib.ocrhip_crnn_seq_len(self._h, 8)) - 2
+        if delta not in (-1, 1):
+            raise RuntimeError('seq_len: recogniser weights are not loaded')
+        return np.asarray(wpad) // 4 + delta
+
     def crnn_forward(self, crops, want_logits=True, want_tokens=False, compute_dtype=F32):
         """crops (n,64,Wpad,1) or (n,64,Wpad) float32 -> dict(logits (n,T,V), tokens (n,T), scores (n,))."""
         assert crops.is_cuda and crops.dtype == torch.float32 and crops.is_contiguous()
         n, hh, Wpad = int(crops.shape[0]), int(crops.shape[1]), int(crops.shape[2])
         if hh != 64:
             raise ValueError('crnn_forward: crops must be 64 pixels high')
-        T, V = Wpad // 4 - 1, self.vocab_size
+        T, V = int(self.seq_len(Wpad)), self.vocab_size
         dev = crops.device
         logits = torch.empty((n, T, V), dtype=torch.float32, device=dev) if want_logits else None
         tokens = torch.empty((n, T), dtype=torch.int32, device=dev) if want_tokens else None
@@ -208,7 +215,7 @@ class HipContext:
         n = int(out_w.shape[0])
         if int(packed.numel()) < 64 * int(out_w.astype(np.int64).sum()):
             raise ValueError('crnn_forward_packed: packed buffer is smaller than the crops it should hold')
-        t_all = out_w // 4 - 1
+        t_all = self.seq_len(out_w)
         tmax, rows = int(t_all.max()), int(t_all.astype(np.int64).sum())
         dev = packed.device
         tokens = torch.empty((n, tmax), dtype=torch.int32, device=dev)

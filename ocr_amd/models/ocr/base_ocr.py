@@ -120,7 +120,7 @@ class BaseOCR:
             toks, sc = res['tokens'].cpu().numpy(), res['scores'].cpu().numpy()
         else:
             from ...utils.ctc_beam import ctc_beam_search
-            T = widths // 4 - 1
+            T = self.ctx.seq_len(widths)
             row0 = np.concatenate([[0], np.cumsum(T)])
             flat = res['logits'].cpu().numpy()
             padded = np.zeros((n, int(T.max()), flat.shape[1]), np.float32)      # pad_batch(pad_value=0.)

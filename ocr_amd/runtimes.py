@@ -45,7 +45,8 @@ class HIPRuntime:
     @staticmethod
     def load_engine(path, *, device=0, state_dict=None, ctx=None, **kwargs):
         """`path`: a torch checkpoint (SakuraRiven east_vgg16.pth or an EasyOCR recogniser .pth), or
-        'random:east[:seed]' / 'random:crnn[:vocab[:seed]]' for seeded random parameters."""
+        'random:east[:seed]' / 'random:crnn[:vocab[:seed[:backbone]]]' (backbone 'vgg' or 'resnet') for seeded
+        random parameters."""
         if state_dict is None:
             if isinstance(path, str) and path.startswith('random:'):
                 parts = path.split(':')
@@ -53,7 +54,8 @@ class HIPRuntime:
                     state_dict = random_east_params(int(parts[2]) if len(parts) > 2 else 0)
                 elif parts[1] == 'crnn':
                     state_dict = random_crnn_params(int(parts[2]) if len(parts) > 2 else 97,
-                                                    seed=int(parts[3]) if len(parts) > 3 else 0)
+                                                    seed=int(parts[3]) if len(parts) > 3 else 0,
+                                                    backbone=parts[4] if len(parts) > 4 else 'vgg')
                 else:
                     raise ValueError('Unknown random model : {}'.format(path))
             else:

@@ -63,16 +63,42 @@ def random_east_params(seed=0):
     return p
 
 
-def random_crnn_params(vocab_size=97, hidden=256, seed=0):
+def resnet_convs():
+    """(conv key, bn key, cin, cout, kernel) of the ResNet extractor (architectures/crnn_arch.py:367-425) under
+    the keys of EasyOCR's ResNet_FeatureExtractor."""
+    pre = 'FeatureExtraction.ConvNet.'
+    out = [(pre + 'conv0_1', pre + 'bn0_1', 1, 32, 3), (pre + 'conv0_2', pre + 'bn0_2', 32, 64, 3)]
+    cin = 64
+    for st, (nb, c) in enumerate(zip((1, 2, 5, 3), (128, 256, 512, 512)), start=1):
+        lay = pre + 'layer%d.' % st
+        if cin != c:
+            out.append((lay + '0.downsample.0', lay + '0.downsample.1', cin, c, 1))
+        for b in range(nb):
+            out.append((lay + '%d.conv1' % b, lay + '%d.bn1' % b, cin if b == 0 else c, c, 3))
+            out.append((lay + '%d.conv2' % b, lay + '%d.bn2' % b, c, c, 3))
+        if st < 4:
+            out.append((pre + 'conv%d' % st, pre + 'bn%d' % st, c, c, 3))
+        cin = c
+    return out + [(pre + 'conv4_1', pre + 'bn4_1', 512, 512, 2), (pre + 'conv4_2', pre + 'bn4_2', 512, 512, 2)]
+
+
+def random_crnn_params(vocab_size=97, hidden=256, seed=0, backbone='vgg'):
     rng = np.random.default_rng(seed)
     p = {}
-    for idx, ci, co, k, bias, bn in CRNN_VGG_CONVS:
-        p['FeatureExtraction.ConvNet.%d.weight' % idx] = _he(rng, co, ci, k)
-        if bias:
-            p['FeatureExtraction.ConvNet.%d.bias' % idx] = _t(rng.standard_normal(co) * 0.05)
-        if bn is not None:
-            _bn(rng, co, 'FeatureExtraction.ConvNet.%d' % bn, p)
-    cin = 256
+    if backbone == 'resnet':
+        for conv, bn, ci, co, k in resnet_convs():
+            p[conv + '.weight'] = _he(rng, co, ci, k)
+            _bn(rng, co, bn, p)
+    elif backbone == 'vgg':
+        for idx, ci, co, k, bias, bn in CRNN_VGG_CONVS:
+            p['FeatureExtraction.ConvNet.%d.weight' % idx] = _he(rng, co, ci, k)
+            if bias:
+                p['FeatureExtraction.ConvNet.%d.bias' % idx] = _t(rng.standard_normal(co) * 0.05)
+            if bn is not None:
+                _bn(rng, co, 'FeatureExtraction.ConvNet.%d' % bn, p)
+    else:
+        raise ValueError('unknown backbone %r' % (backbone,))
+    cin = 512 if backbone == 'resnet' else 256
     for layer in range(2):
         s = 1.0 / math.sqrt(hidden)
         for suffix in ('', '_reverse'):

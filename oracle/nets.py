@@ -1,7 +1,7 @@
 """EAST-VGG16 and CRNN-CTC graphs restated with torch-CPU float32 (test infrastructure).
 
 Follows `architectures/east_arch.py:95-175` and `architectures/crnn_arch.py:38-41,223-226,
-306-328,427-531`.  Keras is not installed here, so the graphs are rebuilt from the layer tables
+306-531` (+ `architectures/current_blocks.py:213-358` for the ResNet blocks).  Keras is not installed here, so the graphs are rebuilt from the layer tables
 with torch functional ops: `conv2d` on explicitly zero-padded inputs, inference batch-norm with
 eps 1e-5, `interpolate(bilinear, align_corners=True)` for the EAST upsampling (what the layer
 itself calls on the torch backend, east_arch.py:44-48), and an explicit LSTM recurrence in Keras
@@ -139,21 +139,51 @@ def east_forward(params, x_nhwc, return_taps=False):
 
 # ----------------------------------------------------------------------------- CRNN
 
-def init_crnn_params(vocab_size=97, hidden=256, seed=0):
-    """Seeded random CRNN (VGG feature extractor, 2 x BiLSTM(hidden) + Linear, Linear(vocab))."""
+# ResNet extractor (crnn_arch.py:367-425 with its defaults): blocks per stage and channels of layer1..4
+RESNET_BLOCKS = [1, 2, 5, 3]
+RESNET_CHANNELS = [128, 256, 512, 512]
+RESNET_BLOCK_BN_EPS = 1e-3        # Conv2DBN default epsilon (current_blocks.py:222); BasicBlock does not override it
+
+
+def resnet_conv_table():
+    """(conv name, bn name, cin, cout, kernel) of every convolution, EasyOCR ResNet_FeatureExtractor keys."""
+    pre = 'FeatureExtraction.ConvNet.'
+    out = [(pre + 'conv0_1', pre + 'bn0_1', 1, 32, 3), (pre + 'conv0_2', pre + 'bn0_2', 32, 64, 3)]
+    cin = 64
+    for st, (nb, c) in enumerate(zip(RESNET_BLOCKS, RESNET_CHANNELS), start=1):
+        lay = pre + 'layer%d.' % st
+        if cin != c:
+            out.append((lay + '0.downsample.0', lay + '0.downsample.1', cin, c, 1))
+        for b in range(nb):
+            out.append((lay + '%d.conv1' % b, lay + '%d.bn1' % b, cin if b == 0 else c, c, 3))
+            out.append((lay + '%d.conv2' % b, lay + '%d.bn2' % b, c, c, 3))
+        if st < 4:
+            out.append((pre + 'conv%d' % st, pre + 'bn%d' % st, c, c, 3))
+        cin = c
+    out += [(pre + 'conv4_1', pre + 'bn4_1', 512, 512, 2), (pre + 'conv4_2', pre + 'bn4_2', 512, 512, 2)]
+    return out
+
+
+def init_crnn_params(vocab_size=97, hidden=256, seed=0, backbone='vgg'):
+    """Seeded random CRNN (VGG or ResNet feature extractor, 2 x BiLSTM(hidden) + Linear, Linear(vocab))."""
     rng = np.random.default_rng(seed)
     p = {}
-    for item in CRNN_VGG_CFG:
-        if item[0] != 'conv':
-            continue
-        _, idx, ci, co, k, bias, bn = item
-        p['FeatureExtraction.ConvNet.%d.weight' % idx] = _he_conv(rng, co, ci, k)
-        if bias:
-            p['FeatureExtraction.ConvNet.%d.bias' % idx] = torch.from_numpy(
-                (rng.standard_normal(co) * 0.05).astype(np.float32))
-        if bn is not None:
-            _bn(rng, co, 'FeatureExtraction.ConvNet.%d' % bn, p)
-    cin = 256
+    if backbone == 'resnet':
+        for conv, bn, ci, co, k in resnet_conv_table():
+            p[conv + '.weight'] = _he_conv(rng, co, ci, k)
+            _bn(rng, co, bn, p)
+    else:
+        for item in CRNN_VGG_CFG:
+            if item[0] != 'conv':
+                continue
+            _, idx, ci, co, k, bias, bn = item
+            p['FeatureExtraction.ConvNet.%d.weight' % idx] = _he_conv(rng, co, ci, k)
+            if bias:
+                p['FeatureExtraction.ConvNet.%d.bias' % idx] = torch.from_numpy(
+                    (rng.standard_normal(co) * 0.05).astype(np.float32))
+            if bn is not None:
+                _bn(rng, co, 'FeatureExtraction.ConvNet.%d' % bn, p)
+    cin = 512 if backbone == 'resnet' else 256
     for layer in range(2):
         for suffix in ('', '_reverse'):
             s = 1.0 / math.sqrt(hidden)
@@ -174,9 +204,54 @@ def init_crnn_params(vocab_size=97, hidden=256, seed=0):
     return p
 
 
+def _conv_bn(x, params, conv, bn, eps, pad=0, stride=1):
+    if pad:
+        x = F.pad(x, (pad, pad, pad, pad))                # ZeroPadding2D + 'valid' (use_manual_padding)
+    x = F.conv2d(x, params[conv + '.weight'], None, stride=stride)
+    g, b, m, v = _bn_of(params, bn)
+    return F.batch_norm(x, m, v, g, b, training=False, eps=eps)
+
+
+@torch.no_grad()
+def crnn_features_resnet(params, x_nhwc):
+    """(B,64,W,1) -> (B,W/4+1,512): the ResNet extractor exactly as the reference graph builds it
+    (crnn_arch.py:330-425): a skip connection only in the first block of layer1-3 (where a 1x1 downsample
+    exists, crnn_arch.py:357), BasicBlock batch-norms with eps 1e-3, stage convolutions with eps 1e-5, zero
+    padding of the width before the (2,1)-strided pooling and before conv4_1."""
+    pre = 'FeatureExtraction.ConvNet.'
+    x = torch.as_tensor(x_nhwc, dtype=torch.float32).permute(0, 3, 1, 2).contiguous()
+    x = F.relu(_conv_bn(x, params, pre + 'conv0_1', pre + 'bn0_1', BN_EPS, pad=1))
+    x = F.relu(_conv_bn(x, params, pre + 'conv0_2', pre + 'bn0_2', BN_EPS, pad=1))
+    for st, (nb, c) in enumerate(zip(RESNET_BLOCKS, RESNET_CHANNELS), start=1):
+        if st in (1, 2):
+            x = F.max_pool2d(x, 2, 2)
+        elif st == 3:
+            x = F.max_pool2d(F.pad(x, (1, 1, 0, 0)), 2, (2, 1))
+        lay = pre + 'layer%d.' % st
+        residual = None
+        if x.shape[1] != c:
+            residual = _conv_bn(x, params, lay + '0.downsample.0', lay + '0.downsample.1', RESNET_BLOCK_BN_EPS)
+        for b in range(nb):
+            y = F.relu(_conv_bn(x, params, lay + '%d.conv1' % b, lay + '%d.bn1' % b, RESNET_BLOCK_BN_EPS, pad=1))
+            y = _conv_bn(y, params, lay + '%d.conv2' % b, lay + '%d.bn2' % b, RESNET_BLOCK_BN_EPS, pad=1)
+            if residual is not None and b == 0:
+                y = y + residual
+            x = F.relu(y)
+        if st < 4:
+            x = F.relu(_conv_bn(x, params, pre + 'conv%d' % st, pre + 'bn%d' % st, BN_EPS, pad=1))
+    x = F.pad(x, (1, 1, 0, 0))
+    x = F.relu(_conv_bn(x, params, pre + 'conv4_1', pre + 'bn4_1', BN_EPS, stride=(2, 1)))
+    x = F.relu(_conv_bn(x, params, pre + 'conv4_2', pre + 'bn4_2', BN_EPS))
+    x = x.mean(dim=2)
+    return x.permute(0, 2, 1).contiguous()
+
+
 @torch.no_grad()
 def crnn_features(params, x_nhwc):
-    """(B,64,W,1) -> (B,T,256): VGG extractor then mean over the 3 remaining rows."""
+    """(B,64,W,1) -> (B,T,C): VGG extractor (C 256, T = W/4 - 1) or, when the parameters are those of the
+    ResNet extractor, crnn_features_resnet (C 512, T = W/4 + 1); then the mean over the 3 remaining rows."""
+    if 'FeatureExtraction.ConvNet.conv0_1.weight' in params:
+        return crnn_features_resnet(params, x_nhwc)
     x = torch.as_tensor(x_nhwc, dtype=torch.float32).permute(0, 3, 1, 2).contiguous()
     for item in CRNN_VGG_CFG:
         if item[0] == 'pool':

@@ -98,3 +98,41 @@ def test_crnn_forward_packed_ragged_matches_per_row_oracle(ctx):
     np.testing.assert_array_equal(out['scores'].cpu().numpy(), rs)
     with pytest.raises(ValueError):
         ctx.crnn_forward_packed(packed, widths[::-1].copy())          # widths must be non-decreasing
+
+
+@pytest.mark.parametrize('n,Wpad', [(2, 128), (3, 64), (1, 208), (2, 16)])
+def test_crnn_resnet_backbone_matches_oracle(ctx, n, Wpad):
+    """`CRNNCTC(backbone='resnet')` (crnn_arch.py:367-425,504-505): 512 features, T = W/4 + 1."""
+    V = 97
+    params = nets.init_crnn_params(vocab_size=V, seed=5, backbone='resnet')
+    ctx.crnn_load_weights(params)
+    try:
+        assert int(ctx.seq_len(Wpad)) == Wpad // 4 + 1
+        rng = np.random.default_rng(n * 1000 + Wpad)
+        x = rng.uniform(-1, 1, (n, 64, Wpad, 1)).astype(np.float32)
+        f = nets.crnn_features(params, x).numpy()
+        ref = nets.crnn_forward(params, x).numpy()
+        out = ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True, want_tokens=True)
+        torch.cuda.synchronize()
+        assert f.shape == (n, Wpad // 4 + 1, 512)
+        _close(ctx.crnn_activation('features').reshape(f.shape), f, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(f).max())))
+        got = out['logits'].cpu().numpy()
+        _close(got, ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+        from oracle import ctc as octc
+        rt, rs = octc.ctc_greedy(got, None, 0)
+        np.testing.assert_array_equal(out['tokens'].cpu().numpy(), rt)
+        np.testing.assert_array_equal(out['scores'].cpu().numpy(), rs)
+        # ragged call: same rows, two widths
+        widths = np.array([Wpad] * n + [Wpad + 32], dtype=np.int32)
+        extra = rng.uniform(-1, 1, (64, Wpad + 32)).astype(np.float32)
+        packed = torch.from_numpy(np.concatenate([x.reshape(-1), extra.reshape(-1)])).cuda()
+        res = ctx.crnn_forward_packed(packed, widths, want_logits=True)
+        torch.cuda.synchronize()
+        T = widths // 4 + 1
+        np.testing.assert_array_equal(res['lengths'].cpu().numpy(), T)
+        flat = res['logits'].cpu().numpy()
+        _close(flat[:n * T[0]].reshape(ref.shape), ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+        ref_extra = nets.crnn_forward(params, extra[None, :, :, None])[0].numpy()
+        _close(flat[n * T[0]:], ref_extra, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref_extra).max())))
+    finally:
+        ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=V, seed=2))      # leave the VGG recogniser loaded

@@ -19,11 +19,12 @@ ap.add_argument('--size', type=int, default=1024)
 ap.add_argument('--crops', type=int, default=1024)
 ap.add_argument('--wpad', type=int, default=192)
 ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--backbone', default='vgg', choices=['vgg', 'resnet'])
 args = ap.parse_args()
 
 ctx = HipContext(0)
 ctx.east_load_weights(random_east_params(1))
-ctx.crnn_load_weights(random_crnn_params(97, seed=2))
+ctx.crnn_load_weights(random_crnn_params(97, seed=2, backbone=args.backbone))
 img = torch.randint(0, 256, (args.batch, args.size, args.size, 3), dtype=torch.uint8, device='cuda')
 crops = torch.rand((args.crops, 64, args.wpad), device='cuda') * 2 - 1
 ctx.east_forward(img)
