@@ -70,6 +70,16 @@ int ocrhip_destroy(ocrhip_handle h);
  * Batch-norm (eps 1e-5) is folded into the preceding convolution at load time. */
 int ocrhip_east_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n);
 
+/* Detector input preparation for pages whose sides are not multiples of 32: replaces the dtype conversion,
+ * the stretch and the normalisation of BaseImageModel.get_image (models/interfaces/base_image_model.py:93-131;
+ * utils/image/image_io.py:126-128; utils/image/image_processing.py:54-79,187-199 with size=None, multiples=32,
+ * antialias=True; utils/image/image_normalization.py:28-39,57):  x/255 (uint8 input only) -> antialiased bilinear
+ * resize, width first then height -> (x - 0.5) / 0.5.
+ *   d_img : device (B,H,W,3) uint8 raw pixels or float32 in [0,1]
+ *   d_out : device (B,out_h,out_w,3) float32, ready for ocrhip_east_forward(in_dtype = OCRHIP_F32) */
+int ocrhip_image_resize_norm(ocrhip_handle h, const void* d_img, int in_dtype, int B, int H, int W, int out_h,
+                             int out_w, float* d_out, ocrhip_stream stream);
+
 /* EAST forward: replaces `compiled_infer(inputs)` in BaseDetector.infer
  * (models/detection/base_detector.py:72-76) and, for in_dtype == OCRHIP_U8, also the
  * `/255` + 'east' normalisation `(x - 0.5) / 0.5` (utils/image/image_normalization.py:57,

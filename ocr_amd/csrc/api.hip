@@ -397,6 +397,13 @@ int ocrhip_east_forward(ocrhip_handle h, const void* d_img, int B, int H, int W,
     return OCRHIP_OK;
 }
 
+int ocrhip_image_resize_norm(ocrhip_handle h, const void* d_img, int in_dtype, int B, int H, int W, int out_h, int out_w,
+                             float* d_out, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    OCR_REQUIRE(in_dtype == OCRHIP_U8 || in_dtype == OCRHIP_F32, "image_resize_norm: input must be uint8 or float32");
+    return launch_resize_rgb_norm(d_img, in_dtype == OCRHIP_U8, B, H, W, out_h, out_w, d_out, (hipStream_t)stream);
+}
+
 int ocrhip_east_get_activation(ocrhip_handle h, const char* name, float* dst, int64_t dst_capacity, int64_t shape[4]) {
     OCR_HANDLE(h);
     return read_activation(h->east.taps, name, dst, dst_capacity, shape);

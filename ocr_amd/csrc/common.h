@@ -186,6 +186,9 @@ int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* 
 int launch_pad_maxpool(const float* x, float* y, int B, int H, int W, int C, int ph, int pw, int sh, int sw, int pad_w,
                        hipStream_t s);
 
+// crop.hip: whole-page `/255` (uint8 only) -> antialiased stretch -> (x-0.5)/0.5, (B,H,W,3) -> float32 (B,oh,ow,3)
+int launch_resize_rgb_norm(const void* img, bool is_u8, int B, int H, int W, int oh, int ow, float* out, hipStream_t s);
+
 // rnn.hip
 int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
 int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, const float* h_prev,

@@ -134,7 +134,85 @@ __global__ __launch_bounds__(256) void crop_resize_pack_kernel(const uint8_t* __
     }
 }
 
+// ---- whole-page resize for the detector input -----------------------------------------------------------
+// `/255` (uint8 input) -> antialiased bilinear stretch to (oh, ow) -> (x - 0.5) / 0.5, 3 channels, same filter
+// arithmetic as above (width first, then height).  Restates base_image_model.py:93-131 with the EAST settings:
+// image_io.py:126-128 (dtype), image_processing.py:54-79,187-199 (stretch to the next multiples of 32) and
+// image_normalization.py:28-39,57.  HBM bound: 3 (or 12) B x source pixels + 12 B x output pixels.
+template <bool U8>
+__device__ __forceinline__ float chan_at(const void* __restrict__ img, int W, int y, int x, int c) {
+    const int64_t i = ((int64_t)y * W + x) * 3 + c;
+    if (U8) return (float)reinterpret_cast<const uint8_t*>(img)[i] / 255.0f;
+    return reinterpret_cast<const float*>(img)[i];
+}
+
+template <bool U8>
+__device__ __forceinline__ float hsample_c(const void* __restrict__ img, int W, int yy, const Axis& ax, int sx, int c) {
+    if (ax.identity) return chan_at<U8>(img, W, yy, sx, c);
+    float center;
+    int lo, cnt;
+    tap_range(ax, sx, center, lo, cnt);
+    float total = 0.0f;
+    for (int j = 0; j < cnt; ++j) total = total + tap_weight(ax, center, lo, j);
+    float acc = 0.0f;
+    for (int j = 0; j < cnt; ++j) {
+        float w = tap_weight(ax, center, lo, j);
+        if (total != 0.0f) w = w / total;
+        const float term = chan_at<U8>(img, W, yy, lo + j, c) * w;
+        acc = (j == 0) ? term : (acc + term);
+    }
+    return acc;
+}
+
+template <bool U8>
+__global__ __launch_bounds__(256) void resize_rgb_norm_kernel(const void* __restrict__ img, int H, int W, int oh, int ow,
+                                                              float* __restrict__ out, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one output element (b, oy, ox, c)
+    if (i >= total) return;
+    const int c = (int)(i % 3);
+    int64_t r = i / 3;
+    const int ox = (int)(r % ow); r /= ow;
+    const int oy = (int)(r % oh);
+    const int64_t b = r / oh;
+    const void* src = U8 ? (const void*)(reinterpret_cast<const uint8_t*>(img) + b * H * W * 3)
+                         : (const void*)(reinterpret_cast<const float*>(img) + b * H * W * 3);
+    const Axis ax = make_axis(W, ow), ay = make_axis(H, oh);
+    float v;
+    if (ay.identity) {
+        v = hsample_c<U8>(src, W, oy, ax, ox, c);
+    } else {
+        float center;
+        int lo, cnt;
+        tap_range(ay, oy, center, lo, cnt);
+        float total_w = 0.0f;
+        for (int j = 0; j < cnt; ++j) total_w = total_w + tap_weight(ay, center, lo, j);
+        v = 0.0f;
+        for (int j = 0; j < cnt; ++j) {
+            float w = tap_weight(ay, center, lo, j);
+            if (total_w != 0.0f) w = w / total_w;
+            const float term = hsample_c<U8>(src, W, lo + j, ax, ox, c) * w;
+            v = (j == 0) ? term : (v + term);
+        }
+    }
+    out[i] = (v - 0.5f) / 0.5f;
+}
+
 }  // namespace
+
+int launch_resize_rgb_norm(const void* img, bool is_u8, int B, int H, int W, int oh, int ow, float* out, hipStream_t s) {
+    OCR_REQUIRE(img && out && B > 0 && H > 0 && W > 0 && oh > 0 && ow > 0, "image_resize: bad arguments B=%d %dx%d -> %dx%d",
+                B, H, W, oh, ow);
+    const int64_t total = (int64_t)B * oh * ow * 3;
+    const int64_t blocks = (total + 255) / 256;
+    OCR_REQUIRE(blocks < (1ll << 31), "image_resize: too large");
+    ProfScope prof("resize_rgb_norm", 0.0, (double)B * H * W * 3 * (is_u8 ? 1.0 : 4.0) + 4.0 * (double)total, s);
+    if (is_u8)
+        hipLaunchKernelGGL(resize_rgb_norm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, img, H, W, oh, ow, out, total);
+    else
+        hipLaunchKernelGGL(resize_rgb_norm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, img, H, W, oh, ow, out, total);
+    OCR_HIP_CHECK(hipGetLastError());
+    return OCRHIP_OK;
+}
 
 int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* rects, const int* box_img,
                             const int* inter, const int* out_w, const int64_t* dst_off, int n, int out_h,

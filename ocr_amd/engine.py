@@ -90,6 +90,22 @@ class HipContext:
         check(self.lib.ocrhip_east_load_weights(self._h, arr, len(arr)))
         self.east_loaded = True
 
+    def image_resize_norm(self, images, out_h, out_w):
+        """images: (B,H,W,3) uint8 raw or float32 in [0,1], on the GPU -> (B,out_h,out_w,3) float32 normalised
+        network input (`/255` for uint8, antialiased bilinear stretch, `(x-0.5)/0.5`)."""
+        assert images.is_cuda and images.dim() == 4 and images.shape[3] == 3 and images.is_contiguous()
+        if images.dtype == torch.uint8:
+            in_dtype = U8
+        elif images.dtype == torch.float32:
+            in_dtype = F32
+        else:
+            raise ValueError('image_resize_norm: images must be uint8 or float32')
+        B, H, W, _ = images.shape
+        out = torch.empty((B, int(out_h), int(out_w), 3), dtype=torch.float32, device=images.device)
+        check(self.lib.ocrhip_image_resize_norm(self._h, _ptr(images), in_dtype, B, H, W, int(out_h), int(out_w),
+                                                _ptr(out), _stream()))
+        return out
+
     def east_forward(self, images, compute_dtype=F32):
         """images: (B,H,W,3) uint8 raw or float32 normalised, on the GPU -> (B,H/4,W/4,6) float32."""
         assert images.is_cuda and images.dim() == 4 and images.shape[3] == 3 and images.is_contiguous()

@@ -72,14 +72,13 @@ class EAST:
         if image.dtype == np.uint8 and (oh, ow) == (h, w) and image.shape[2] == 3:
             return torch.from_numpy(np.ascontiguousarray(image)).to(self.ctx.device)
         x = torch.from_numpy(np.ascontiguousarray(image)).to(self.ctx.device)
-        x = x.float() / 255 if image.dtype == np.uint8 else x.float()
+        if x.dtype != torch.uint8:
+            x = x.float()
         if x.shape[2] == 1:
             x = x.expand(-1, -1, 3)
-        if (oh, ow) != (h, w):
-            # stretch to the next multiples of 32 (image_processing.py:187-199), antialiased bilinear
-            x = torch.nn.functional.interpolate(x.permute(2, 0, 1)[None], size=(oh, ow), mode='bilinear',
-                                                antialias=True, align_corners=False)[0].permute(1, 2, 0)
-        return ((x - 0.5) / 0.5).contiguous()
+        # `/255` (uint8), stretch to the next multiples of 32 (image_processing.py:187-199, antialiased bilinear;
+        # the identity when the size already fits) and `(x-0.5)/0.5`, in one kernel of the library
+        return self.ctx.image_resize_norm(x[None].contiguous(), oh, ow)[0]
 
     # ---- inference ---------------------------------------------------------------------------
     def infer(self, image, *, predicted=None, overwrite=False, **kwargs):

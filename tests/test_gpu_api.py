@@ -45,6 +45,14 @@ def test_east_input_not_multiple_of_32(models):
     assert tuple(x.shape) == (256, 416, 3)
     ref_in = oimg.prepare_east_input(img)
     np.testing.assert_allclose(x.cpu().numpy(), ref_in, rtol=0, atol=2e-5)
+    # bit-exact against the NumPy restatement of the same filter (float32 taps, width first, then height)
+    np.testing.assert_array_equal(x.cpu().numpy(), oimg.prepare_east_input(img, resize='numpy'))
+    # any target size, float input, batch of two: a down-scaling (wide filter support) and an up-scaling axis
+    f = (rng.integers(0, 256, (2, 75, 130, 3)) / 255).astype(np.float32)
+    y = east.ctx.image_resize_norm(torch.from_numpy(f).cuda(), 32, 160).cpu().numpy()
+    for b in range(2):
+        np.testing.assert_array_equal(y[b], oimg.normalize_mean_std(oimg.aa_resize_numpy(f[b], 32, 160)))
+        np.testing.assert_allclose(y[b], oimg.normalize_mean_std(oimg.aa_resize_torch(f[b], 32, 160)), rtol=0, atol=2e-6)
     out = east.infer(img)['output']
     ref = nets.east_forward(ep, ref_in[None])[0].numpy()
     np.testing.assert_allclose(out, ref, rtol=2e-4, atol=2e-5)
