@@ -61,6 +61,12 @@ const char* ocrhip_last_error(void);
 int ocrhip_create(int device, ocrhip_handle* out);
 int ocrhip_destroy(ocrhip_handle h);
 
+/* Options of a handle (no counterpart in the reference; Keras picks its convolution algorithm itself).
+ *   "conv3x3_winograd": 1 (default) computes the 3x3 convolutions with >= 64 output channels by Winograd
+ *   F(2x2,3x3) in float32 (2.25x fewer multiplications, results within float32 rounding of the direct sum);
+ *   0 computes them as a direct implicit GEMM (a float32 fma chain over the taps and channels). */
+int ocrhip_set_option(ocrhip_handle h, const char* name, int value);
+
 /* ------------------------------------------------------------------------------------ EAST --
  * Weights of EASTVGG (architectures/east_arch.py:95-175), keys of SakuraRiven's east_vgg16.pth:
  *   extractor.features.{0,3,7,10,14,17,20,24,27,30,34,37,40}.{weight,bias}   conv 3x3

@@ -23,6 +23,10 @@ static thread_local Profiler* g_prof = nullptr;
 Profiler* current_profiler() { return g_prof; }
 void set_current_profiler(Profiler* p) { g_prof = p; }
 
+static thread_local int g_conv3x3_winograd = 1;
+int conv3x3_winograd() { return g_conv3x3_winograd; }
+void set_conv3x3_winograd(int on) { g_conv3x3_winograd = on; }
+
 hipEvent_t Profiler::get_event() {
     if (!pool.empty()) {
         hipEvent_t e = pool.back();
@@ -221,6 +225,7 @@ using namespace ocrhip;
         }                                                           \
         OCR_HIP_CHECK(hipSetDevice((h)->device));                   \
         ocrhip::set_current_profiler(&(h)->prof);                   \
+        ocrhip::set_conv3x3_winograd((h)->conv3x3_winograd);        \
     } while (0)
 
 extern "C" {
@@ -251,7 +256,8 @@ int ocrhip_destroy(ocrhip_handle h) {
     if (!h) return OCRHIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.bias.release(); };
+    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.bias.release(); };
+    for (auto& L : h->crnn.rconv) free_layer(L);
     for (auto& L : h->east.vgg) free_layer(L);
     for (auto& L : h->east.merge) free_layer(L);
     free_layer(h->east.head);
@@ -765,6 +771,18 @@ int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int 
                       int* d_tokens, float* d_scores, ocrhip_stream stream) {
     OCR_HANDLE(h);
     return launch_ctc_greedy(d_logits, B, T, V, V, d_lengths, nullptr, blank, d_tokens, d_scores, (hipStream_t)stream);
+}
+
+int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
+    OCR_HANDLE(h);
+    OCR_REQUIRE(name, "set_option: null name");
+    if (std::strcmp(name, "conv3x3_winograd") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: conv3x3_winograd is 0 or 1");
+        h->conv3x3_winograd = value;
+        return OCRHIP_OK;
+    }
+    set_error("set_option: unknown option '%s'", name);
+    return OCRHIP_EINVAL;
 }
 
 int ocrhip_profile_enable(ocrhip_handle h, int enable) {

@@ -31,6 +31,7 @@ SOURCES = {
     'ctc.hip': ['-ffp-contract=off'],
     'conv_direct.hip': [],
     'conv_mfma.hip': [],
+    'conv_wino.hip': [],
     'rnn.hip': [],
     'pool.hip': [],
 }

@@ -92,6 +92,7 @@ struct ConvLayer {
     int cin = 0, cout = 0, ks = 0;
     int cout_pad = 0;       // cout rounded up to the kernel's N tile
     DevBuf w_f32;           // MFMA slab layout (see conv_mfma.hip) or direct layout (see conv_direct.hip)
+    DevBuf w_wino;          // 3x3 layers with >= 64 output channels: Winograd-transformed filters (see conv_wino.hip)
     DevBuf bias;            // cout_pad floats, folded
     bool direct = false;    // small-Cin direct kernel layout
 };
@@ -143,6 +144,7 @@ struct ocrhip_ctx {
     ocrhip::CrnnNet crnn;
     ocrhip::DevBuf decode_stage;   // staging of the decode kernel
     ocrhip::DevBuf lanms_ws;       // scratch of the LANMS kernel
+    int conv3x3_winograd = 1;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     ocrhip::Profiler prof;
 };
 
@@ -159,6 +161,14 @@ int prepare_conv_mfma(ConvLayer& L, const float* w_oihw, const float* bias, int 
 //   residual != nullptr (unpooled ks 3 / 2 only): a tensor shaped like y, added before the ReLU.
 int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
                      const float* up_src, int up_c, hipStream_t s, const float* residual = nullptr);
+
+// conv_wino.hip: the same 3x3 layers by Winograd F(2x2,3x3) (cout_pad % 64 == 0, cin % 8 == 0); launch_conv_mfma
+// forwards to it when the handle's "conv3x3_winograd" option is on (the default).
+int prepare_conv_wino(ConvLayer& L, const float* w_oihw, int cout, int cin);
+int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
+                     const float* residual, hipStream_t s);
+int conv3x3_winograd();              // option of the handle in use on this thread
+void set_conv3x3_winograd(int on);
 
 // conv_direct.hip: first layers (Cin 3 or 1) and the 32->6 sigmoid heads.
 int prepare_conv_direct(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);

@@ -392,6 +392,7 @@ int prepare_conv_mfma(ConvLayer& L, const float* w_oihw, const float* bias, int 
     OCR_TRY(L.bias.reserve(bpad.size() * sizeof(float)));
     OCR_HIP_CHECK(hipMemcpy(L.w_f32.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     OCR_HIP_CHECK(hipMemcpy(L.bias.ptr, bpad.data(), bpad.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (ks == 3 && BN == 64 && cin % 8 == 0) OCR_TRY(prepare_conv_wino(L, w_oihw, cout, cin));
     return OCRHIP_OK;
 }
 
@@ -400,6 +401,8 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
     OCR_REQUIRE(!L.direct && L.w_f32.ptr, "conv_mfma: layer not prepared");
     OCR_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "conv_mfma: bad arguments B=%d H=%d W=%d", B, H, W);
     const int ks = L.ks;
+    if (ks == 3 && L.w_wino.ptr && !up_src && conv3x3_winograd())
+        return launch_conv_wino(L, x, y, B, H, W, pool, relu, residual, s);
     const int BN = (L.cout_pad % 64 == 0) ? 64 : 32;
     const int NT = BN / 32;
     ConvArgs a;

@@ -90,6 +90,10 @@ class HipContext:
         check(self.lib.ocrhip_east_load_weights(self._h, arr, len(arr)))
         self.east_loaded = True
 
+    def set_option(self, name, value):
+        """'conv3x3_winograd': 1 (default) Winograd F(2x2,3x3) for the wide 3x3 convolutions, 0 direct implicit GEMM."""
+        check(self.lib.ocrhip_set_option(self._h, name.encode(), int(value)))
+
     def image_resize_norm(self, images, out_h, out_w):
         """images: (B,H,W,3) uint8 raw or float32 in [0,1], on the GPU -> (B,out_h,out_w,3) float32 normalised
         network input (`/255` for uint8, antialiased bilinear stretch, `(x-0.5)/0.5`)."""

@@ -136,3 +136,30 @@ def test_crnn_resnet_backbone_matches_oracle(ctx, n, Wpad):
         _close(flat[n * T[0]:], ref_extra, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref_extra).max())))
     finally:
         ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=V, seed=2))      # leave the VGG recogniser loaded
+
+
+def test_direct_3x3_path_matches_oracle_too(ctx):
+    """`conv3x3_winograd = 0`: the 3x3 layers as a direct implicit GEMM (the default is Winograd F(2x2,3x3));
+    both agree with the oracle to the stated tolerance and with each other."""
+    params = nets.init_east_params(seed=1)
+    ctx.east_load_weights(params)
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (1, 96, 160, 3), dtype=np.uint8)
+    ref = nets.east_forward(params, np.stack([oimg.prepare_east_input(i) for i in img])).numpy()
+    wino = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
+    ctx.set_option('conv3x3_winograd', 0)
+    try:
+        direct = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
+        cp = nets.init_crnn_params(vocab_size=97, seed=2)
+        ctx.crnn_load_weights(cp)
+        x = rng.uniform(-1, 1, (3, 64, 144, 1)).astype(np.float32)
+        got = ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True)['logits'].cpu().numpy()
+        cref = nets.crnn_forward(cp, x).numpy()
+        _close(got, cref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(cref).max())))
+    finally:
+        ctx.set_option('conv3x3_winograd', 1)
+    _close(direct, ref, rtol=1e-4, atol=1e-5)
+    _close(wino, ref, rtol=1e-4, atol=1e-5)
+    _close(wino, direct, rtol=1e-4, atol=1e-5)
+    with pytest.raises(ValueError):
+        ctx.set_option('no_such_option', 1)
