@@ -31,7 +31,7 @@ SOURCES = {
     'ctc.hip': ['-ffp-contract=off'],
     'conv_direct.hip': [],
     'conv_mfma.hip': [],
-    'conv_wino.hip': [],
+    'conv_wino.hip': ['-fno-slp-vectorize'],
     'rnn.hip': [],
     'pool.hip': [],
 }
