@@ -23,6 +23,9 @@ static thread_local Profiler* g_prof = nullptr;
 Profiler* current_profiler() { return g_prof; }
 void set_current_profiler(Profiler* p) { g_prof = p; }
 
+static thread_local int g_lstm_persistent = 1;
+int lstm_persistent() { return g_lstm_persistent; }
+void set_lstm_persistent(int on) { g_lstm_persistent = on; }
 static thread_local int g_conv3x3_winograd = 1;
 int conv3x3_winograd() { return g_conv3x3_winograd; }
 void set_conv3x3_winograd(int on) { g_conv3x3_winograd = on; }
@@ -226,6 +229,7 @@ using namespace ocrhip;
         OCR_HIP_CHECK(hipSetDevice((h)->device));                   \
         ocrhip::set_current_profiler(&(h)->prof);                   \
         ocrhip::set_conv3x3_winograd((h)->conv3x3_winograd);        \
+        ocrhip::set_lstm_persistent((h)->lstm_persistent);          \
     } while (0)
 
 extern "C" {
@@ -273,7 +277,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     }
     free_layer(h->crnn.pred);
     for (auto& b : h->crnn.act) b.release();
-    for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits, &h->crnn.meta})
+    for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits, &h->crnn.meta, &h->crnn.lstm_counters})
         b->release();
     h->crnn.ring.release();
     h->decode_stage.release();
@@ -627,7 +631,7 @@ static int crnn_features(CrnnNet& net, const float* x, int n, int Wpad, float* f
 // Uniform mode: seq_T == nullptr, every sequence has Tmax steps.  Ragged mode: host_T (non-decreasing)
 // and the device arrays d_T / d_row0 describe the sequences.
 static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int Tmax, const int* host_T,
-                         const int* d_T, const int* d_row0, float* logits, hipStream_t s) {
+                         const int* d_T, const int* d_row0, const int* d_active, float* logits, hipStream_t s) {
     const int Hd = net.hidden;
     OCR_REQUIRE(R < (1ll << 31), "crnn: too many time steps in one batch");
     OCR_TRY(net.xw.reserve((size_t)2 * R * 4 * Hd * sizeof(float)));
@@ -635,6 +639,7 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
     OCR_TRY(net.cbuf.reserve((size_t)2 * n * Hd * sizeof(float)));
     OCR_TRY(net.seq.reserve((size_t)R * 2 * Hd * sizeof(float)));
     OCR_TRY(net.lin.reserve((size_t)2 * R * Hd * sizeof(float)));
+    OCR_TRY(net.lstm_counters.reserve(2 * 16 * sizeof(unsigned)));
     const float* layer_in = feats;
     for (int l = 0; l < 2; ++l) {
         float* xw_f = net.xw.as<float>();
@@ -647,8 +652,13 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
             // one timer scope for the whole recurrence of a layer (Tmax launches, both directions each)
             ProfScope prof("lstm_layer(T steps)", 2.0 * 2 * 4.0 * Hd * Hd * (double)(R - n),
                            4.0 * (2.0 * R * 4 * Hd + (double)R * 2 * Hd) + 4.0 * 2 * 4 * Hd * Hd * Tmax, s);
+            int rc = OCRHIP_ESTATE;
+            if (lstm_persistent())
+                rc = launch_lstm_layer(xw_f, xw_b, net.whh[l][0].as<float>(), net.whh[l][1].as<float>(), hb0, net.cbuf.as<float>(),
+                                       net.seq.as<float>(), n, Tmax, d_T, d_row0, d_active, net.lstm_counters.as<unsigned>(), s);
+            if (rc != OCRHIP_OK && rc != OCRHIP_ESTATE) return rc;
             int first = 0;
-            for (int step = 0; step < Tmax; ++step) {
+            for (int step = 0; rc == OCRHIP_ESTATE && step < Tmax; ++step) {          // one launch per time step instead
                 if (host_T)
                     while (first < n && host_T[first] <= step) ++first;     // sequences shorter than step+1 are done
                 const float* hp = (step & 1) ? hb1 : hb0;
@@ -693,7 +703,7 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
         OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));
         logits = net.logits.as<float>();
     }
-    OCR_TRY(crnn_sequence(net, feats, n, R, T, nullptr, nullptr, nullptr, logits, s));
+    OCR_TRY(crnn_sequence(net, feats, n, R, T, nullptr, nullptr, nullptr, nullptr, logits, s));
     if (d_tokens) OCR_TRY(launch_ctc_greedy(logits, n, T, net.vocab, net.vocab, nullptr, nullptr, 0, d_tokens, d_scores, s));
     return OCRHIP_OK;
 }
@@ -713,7 +723,7 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
     OCR_REQUIRE(!d_tokens || d_scores, "crnn_forward_packed: d_scores is required with d_tokens");
     hipStream_t s = (hipStream_t)stream;
     const int Fc = net.feat_c;
-    std::vector<int> meta((size_t)2 * n);        // [T of each crop | first row of each crop]
+    std::vector<int> meta((size_t)2 * n);        // [T of each crop | first row of each crop | crops with more than t steps, per t]
     int64_t R = 0;
     for (int i = 0; i < n; ++i) {
         OCR_REQUIRE(out_w[i] >= 8 && out_w[i] % 4 == 0 && (i == 0 || out_w[i] >= out_w[i - 1]),
@@ -725,10 +735,17 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
     }
     const int Tmax = meta[n - 1];
     OCR_REQUIRE(!d_tokens || t_stride >= Tmax, "crnn_forward_packed: t_stride %d is smaller than the longest sequence %d", t_stride, Tmax);
+    OCR_REQUIRE(Tmax >= 1, "crnn_forward_packed: crops too narrow");
+    meta.resize((size_t)2 * n + Tmax);
+    for (int t = 0, first = 0; t < Tmax; ++t) {
+        while (first < n && meta[first] <= t) ++first;
+        meta[(size_t)2 * n + t] = n - first;
+    }
     OCR_TRY(net.meta.reserve(meta.size() * sizeof(int)));
     OCR_TRY(net.ring.upload(net.meta.ptr, meta.data(), meta.size() * sizeof(int), s));
     const int* d_T = net.meta.as<int>();
     const int* d_row0 = d_T + n;
+    const int* d_active = d_row0 + n;
     if (d_lengths) OCR_HIP_CHECK(hipMemcpyAsync(d_lengths, d_T, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, s));
 
     OCR_TRY(net.feats.reserve((size_t)R * Fc * sizeof(float)));
@@ -756,7 +773,7 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
         OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));
         logits = net.logits.as<float>();
     }
-    OCR_TRY(crnn_sequence(net, feats, n, R, Tmax, meta.data(), d_T, d_row0, logits, s));
+    OCR_TRY(crnn_sequence(net, feats, n, R, Tmax, meta.data(), d_T, d_row0, d_active, logits, s));
     if (d_tokens)
         OCR_TRY(launch_ctc_greedy(logits, n, t_stride, net.vocab, net.vocab, d_T, d_row0, 0, d_tokens, d_scores, s));
     return OCRHIP_OK;
@@ -779,6 +796,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "conv3x3_winograd") == 0) {
         OCR_REQUIRE(value == 0 || value == 1, "set_option: conv3x3_winograd is 0 or 1");
         h->conv3x3_winograd = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "lstm_persistent") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: lstm_persistent is 0 or 1");
+        h->lstm_persistent = value;
         return OCRHIP_OK;
     }
     set_error("set_option: unknown option '%s'", name);

@@ -33,6 +33,7 @@ SOURCES = {
     'conv_mfma.hip': [],
     'conv_wino.hip': ['-fno-slp-vectorize'],
     'rnn.hip': [],
+    'rnn_persistent.hip': [],
     'pool.hip': [],
 }
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 'ocrhip.h')]

@@ -131,7 +131,7 @@ struct CrnnNet {
     ConvLayer linear[2];     // 512 -> 256
     ConvLayer pred;          // 256 -> vocab
     DevBuf act[3];
-    DevBuf feats, xw, hbuf, cbuf, seq, lin, logits, meta;
+    DevBuf feats, xw, hbuf, cbuf, seq, lin, logits, meta, lstm_counters;
     PinnedRing ring;
     std::map<std::string, Activation> taps;
 };
@@ -144,6 +144,7 @@ struct ocrhip_ctx {
     ocrhip::CrnnNet crnn;
     ocrhip::DevBuf decode_stage;   // staging of the decode kernel
     ocrhip::DevBuf lanms_ws;       // scratch of the LANMS kernel
+    int lstm_persistent = 1;       // recurrence of a BiLSTM layer in one persistent launch (1) or one launch per step (0)
     int conv3x3_winograd = 1;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     ocrhip::Profiler prof;
 };
@@ -204,6 +205,14 @@ int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipSt
 int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, const float* h_prev,
                      float* h_next, float* c_state, float* out, int n, int T, int step, const int* seq_T,
                      const int* seq_row0, int first, hipStream_t s);
+
+// rnn_persistent.hip: a whole bidirectional layer in one cooperative launch (hbuf: 2 parities x 2 directions x n x 256,
+// counters: 32 unsigned ints).  OCRHIP_ESTATE when the device cannot hold the grid at once (use the per-step kernel).
+int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, float* hbuf, float* cbuf,
+                      float* out, int n, int T, const int* seq_T, const int* seq_row0, const int* step_active,
+                      unsigned* counters, hipStream_t s);
+int lstm_persistent();               // option of the handle in use on this thread
+void set_lstm_persistent(int on);
 
 // ctc.hip
 // row0 != nullptr: sequence b starts at row row0[b] of a flat (sum T, ld_v) logits matrix; T is then the

@@ -163,3 +163,24 @@ def test_direct_3x3_path_matches_oracle_too(ctx):
     _close(wino, direct, rtol=1e-4, atol=1e-5)
     with pytest.raises(ValueError):
         ctx.set_option('no_such_option', 1)
+
+
+def test_lstm_per_step_launches_match_the_persistent_layer(ctx):
+    """`lstm_persistent = 0` (one launch per time step) against the default single persistent launch per layer:
+    same cell arithmetic, different k order inside the matrix cores."""
+    V = 97
+    params = nets.init_crnn_params(vocab_size=V, seed=11)
+    ctx.crnn_load_weights(params)
+    rng = np.random.default_rng(5)
+    widths = np.array([64] * 5 + [96] * 40 + [128] * 150 + [256] * 3 + [512], dtype=np.int32)
+    packed = torch.from_numpy(rng.uniform(-1, 1, int(64 * widths.sum())).astype(np.float32)).cuda()
+    a = ctx.crnn_forward_packed(packed, widths, want_logits=True)
+    ctx.set_option('lstm_persistent', 0)
+    try:
+        b = ctx.crnn_forward_packed(packed, widths, want_logits=True)
+    finally:
+        ctx.set_option('lstm_persistent', 1)
+    torch.cuda.synchronize()
+    la, lb = a['logits'].cpu().numpy(), b['logits'].cpu().numpy()
+    _close(la, lb, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(lb).max())))
+    np.testing.assert_array_equal(a['lengths'].cpu().numpy(), b['lengths'].cpu().numpy())
