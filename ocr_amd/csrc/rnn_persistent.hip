@@ -34,8 +34,8 @@ namespace {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kH = 256;            // hidden units
-constexpr int kRows = 128;         // sequences per pass of a workgroup
-constexpr int kKC = 32;            // k values per staged chunk of h
+constexpr int kRows = 112;         // sequences per pass of a workgroup (7 tiles of 16: what fits beside W_hh in 160 KB)
+constexpr int kKC = 64;            // k values per staged chunk of h
 constexpr int kAS = kKC + 4;       // floats per staged row of h
 constexpr int kWFloats = 128 * kH; // W_hh slice
 constexpr int kLdsBytes = (kWFloats + kRows * kAS) * 4;
@@ -53,7 +53,10 @@ struct LayerArgs {
     int n, T, G;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// logistic and tanh on the hardware exp2 / reciprocal (1 ulp each): the cell update of 14 elements per lane sits on
+// the critical path of every step
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // h is the only data that moves between workgroups while the kernel runs.  It is written and read with relaxed
 // agent-scope atomic accesses: they go to the point where all CUs (of all XCDs) agree, so the hand-over needs no
@@ -112,21 +115,22 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
 
     const int hi = (lane >> 3) & 1;
     const int unit = u0 + 8 * wave + (l16 & 7);
-    const int srow = tid >> 3, scol = (tid & 7) * 4;          // staging map: 8 lanes per row, 32 rows per sweep
+    const int srow = tid >> 4, scol = (tid & 15) * 4;         // staging map: 16 lanes per row, 16 rows per sweep
 
     // Everything a cell update needs besides h_{t-1} W_hh^T is fetched before the wait for h_{t-1}: the input
     // projections xw of the lane's elements, their cell state and their row numbers.
-    float xwv[8][2][4], cpv[8][2];
-    int rowv[8][2], sv[8][2];
+    float xwv[7][2][4], cpv[7][2];
+    int rowv[7][2], sv[7][2];
     auto prefetch_cells = [&](int t, int p, int rows_here) {
         const int tiles_here = (rows_here + 15) >> 4;
 #pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
+        for (int rt = 0; rt < 7; ++rt) {
+            sv[rt][0] = -1;
+            sv[rt][1] = -1;
             if (rt >= tiles_here) continue;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int j = rt * 16 + 4 * lg + 2 * hi + k;
-                sv[rt][k] = -1;
                 if (j >= rows_here) continue;
                 const int s = n - 1 - ((p * kRows + j) * G + g);
                 const int Ts = a.seq_T ? a.seq_T[s] : a.T;
@@ -139,6 +143,19 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
                 sv[rt][k] = s;
             }
         }
+    };
+
+    // cell state and layer output of the elements just finished (kept in cpv / xwv[.][.][0] by the cell update)
+    auto flush_cells = [&]() {
+#pragma unroll
+        for (int rt = 0; rt < 7; ++rt)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int s = sv[rt][k];
+                if (s < 0) continue;
+                a.cbuf[((int64_t)dir * n + s) * kH + unit] = cpv[rt][k];
+                a.out[(int64_t)rowv[rt][k] * (2 * kH) + dir * kH + unit] = xwv[rt][k][0];
+            }
     };
 
     for (int t = 0; t < a.T; ++t) {
@@ -165,43 +182,46 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
             const int rows_here = min(kRows, act_local - p * kRows);         // active rows of this pass
             if (rows_here <= 0) break;
             const int tiles_here = (rows_here + 15) >> 4;
-            if (p > 0) prefetch_cells(t, p, rows_here);
+            if (p > 0) {
+                flush_cells();
+                prefetch_cells(t, p, rows_here);
+            }
 
-            floatx4 acc[8][2];
+            floatx4 acc[7][2];
 #pragma unroll
-            for (int rt = 0; rt < 8; ++rt)
+            for (int rt = 0; rt < 7; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) acc[rt][ct][v] = 0.0f;
 
             if (t > 0) {
-                int64_t hoff[4];
+                int64_t hoff[7];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int j = srow + i * 32;
+                for (int i = 0; i < 7; ++i) {
+                    const int j = srow + i * 16;
                     const int d = (p * kRows + j) * G + g;
                     hoff[i] = (j < rows_here) ? (int64_t)(n - 1 - d) * kH + scol : -1;
                 }
-                // the k chunks of h_{t-1} travel global -> registers -> LDS, four chunks ahead of their use
-                float4 ra[4][4];
+                // the k chunks of h_{t-1} travel global -> registers -> LDS, two chunks ahead of their use
+                float4 ra[2][7];
                 auto load_chunk = [&](int kc, int slot) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 7; ++i)
                         ra[slot][i] = (hoff[i] >= 0) ? load_h4(hprev + hoff[i] + kc * kKC) : make_float4(0.f, 0.f, 0.f, 0.f);
                 };
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) load_chunk(kc, kc);
+                load_chunk(0, 0);
+                load_chunk(1, 1);
 #pragma unroll
                 for (int kc = 0; kc < kH / kKC; ++kc) {
                     __syncthreads();                                         // previous chunk fully read
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[(srow + i * 32) * kAS + scol]) = ra[kc & 3][i];
+                    for (int i = 0; i < 7; ++i) *reinterpret_cast<float4*>(&As[(srow + i * 16) * kAS + scol]) = ra[kc & 1][i];
                     __syncthreads();
-                    if (kc + 4 < kH / kKC) load_chunk(kc + 4, kc & 3);
+                    if (kc + 2 < kH / kKC) load_chunk(kc + 2, kc & 1);
 #pragma unroll
-                    for (int cbl = 0; cbl < 2; ++cbl) {                      // 16 k values per block
-                        const int c = (kc * 2 + cbl) * 4 + lg;               // 16-byte slot of W_hh rows
+                    for (int cbl = 0; cbl < kKC / 16; ++cbl) {               // 16 k values per block
+                        const int c = (kc * (kKC / 16) + cbl) * 4 + lg;      // 16-byte slot of W_hh rows
                         float4 b4[2];
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) {
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
                             b4[ct] = *reinterpret_cast<const float4*>(&Ws[(R * 64 + (c ^ (R & 15))) * 4]);
                         }
 #pragma unroll
-                        for (int rt = 0; rt < 8; ++rt) {
+                        for (int rt = 0; rt < 7; ++rt) {
                             if (rt < tiles_here) {
                                 const float4 a4 = *reinterpret_cast<const float4*>(&As[(rt * 16 + l16) * kAS + cbl * 16 + lg * 4]);
 #pragma unroll
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
             // unit (ct 0: gates i, f; ct 1: gates g, o).  Lanes l and l ^ 8 hold the two halves of an element's gates: the
             // lane with bit 3 clear finishes rows v = 0, 1, its partner rows v = 2, 3.
 #pragma unroll
-            for (int rt = 0; rt < 8; ++rt) {
+            for (int rt = 0; rt < 7; ++rt) {
                 if (rt >= tiles_here) continue;
                 float mine[2][2], theirs[2][2];          // [ct][row of my pair]
 #pragma unroll
@@ -250,18 +270,19 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
                     const float zf = xwv[rt][k][1] + (hi ? mine[0][k] : theirs[0][k]);
                     const float zg = xwv[rt][k][2] + (hi ? theirs[1][k] : mine[1][k]);
                     const float zo = xwv[rt][k][3] + (hi ? mine[1][k] : theirs[1][k]);
-                    const float c = sigmoidf_(zf) * cpv[rt][k] + sigmoidf_(zi) * tanhf(zg);
-                    const float hval = sigmoidf_(zo) * tanhf(c);
-                    a.cbuf[((int64_t)dir * n + s) * kH + unit] = c;
+                    const float c = sigmoidf_(zf) * cpv[rt][k] + sigmoidf_(zi) * tanhf_(zg);
+                    const float hval = sigmoidf_(zo) * tanhf_(c);
                     store_h(hnext + (int64_t)s * kH + unit, hval);
-                    a.out[(int64_t)rowv[rt][k] * (2 * kH) + dir * kH + unit] = hval;
+                    cpv[rt][k] = c;                  // written out, with the layer output, after h_t is published
+                    xwv[rt][k][0] = hval;
                 }
             }
         }
-        // publish h_t
+        // publish h_t, then write what only this workgroup reads again
         __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this thread's h stores have reached the coherence point
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flush_cells();
     }
 }
 
