@@ -144,16 +144,18 @@ class OcrPipeline:
         detected, recognised = None, None
         for images, maps_override in batches:
             nxt = self._stage_detect(images, maps_override)
+            # the recognition of the batch detected one turn ago is enqueued before the host turns to the strings of the
+            # batch before it: the GPU queue never runs dry, also not at the end of the stream
+            newer = self._stage_recognise(detected) if detected is not None else None
             if recognised is not None:
                 yield self._stage_strings(recognised)
-                recognised = None
-            if detected is not None:
-                recognised = self._stage_recognise(detected)
+            recognised = newer
             detected = nxt
+        newer = self._stage_recognise(detected) if detected is not None else None
         if recognised is not None:
             yield self._stage_strings(recognised)
-        if detected is not None:
-            yield self._stage_strings(self._stage_recognise(detected))
+        if newer is not None:
+            yield self._stage_strings(newer)
 
     def recognise(self, images, boxes_per_image):
         """images (B,H,W,3) uint8 GPU; boxes_per_image: list of (m_b,4) float32 relative xyxy (host)
