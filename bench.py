@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense f32 matrix peak (= f32 vector peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X dense bf16 matrix peak
 HBM_PEAK_GBS = 8000.0
 
 
@@ -42,6 +43,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=8, help='pages per step and per GPU')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--words', type=int, default=220)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="f32 = the reference's precision (the headline); bf16 = bfloat16 operands, float32 accumulation")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-pages', type=int, default=4)
     return ap.parse_args()
@@ -88,7 +91,8 @@ def main():
 
     east_params = random_east_params(seed=1)
     crnn_params = random_crnn_params(vocab_size=97, seed=2)
-    pipe = OcrPipeline(east_params, crnn_params, device=local_rank)
+    from ocr_amd._lib import BF16, F32
+    pipe = OcrPipeline(east_params, crnn_params, device=local_rank, compute_dtype=BF16 if args.dtype == 'bf16' else F32)
 
     B, S = args.batch, args.size
     images, maps, _ = synth.make_pages(1234 + 4 + 100 * rank, B, S, S, args.words)
@@ -125,19 +129,21 @@ def main():
 
     if rank == 0:
         pages = world * args.steps * B
-        mfma = [s for s in stats if s['flops'] > 0 and s['name'].startswith(('conv_mfma', 'conv_wino'))]
+        mfma = [s for s in stats if s['flops'] > 0 and s['name'].startswith(('conv_mfma', 'conv_wino', 'conv_bf16'))]
         dom = max(mfma, key=lambda s: s['total_ms'])
         achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
         # the Winograd kernel is credited with the flop count of the convolution it computes (2*9*Cin*Cout per output
         # pixel) but its matrix cores execute 16/36 of that: `executed` is what the MFMA peak actually bounds
         executed = achieved * (16.0 / 36.0 if dom['name'].startswith('conv_wino') else 1.0)
+        peak = BF16_MFMA_PEAK_TFLOPS if dom['name'].startswith('conv_bf16') else F32_MFMA_PEAK_TFLOPS
         gpu_ms = sum(s['total_ms'] for s in stats)
         conv_ms = sum(s['total_ms'] for s in mfma)
         conv_tflops = sum(s['flops'] for s in mfma) / (conv_ms * 1e-3) / 1e12
         line = {
             'metric': 'end-to-end OCR images/sec (1024x1024 page)', 'value': pages / elapsed, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.dtype == 'f32' else 'bf16 operands, f32 accumulate (non-default variant)', 'data': 'synthetic',
             'config': {'workload': 'configs[3]: full EAST->crop->CRNN pipeline on synthetic %dx%d dense-text pages' % (S, S),
                        'pages_per_step_per_gpu': B, 'words_per_page': words / B, 'decode_candidates_per_page': None,
                        'detector_maps': 'teacher maps of the rendered pages feed decode; the random-weight EAST forward '
@@ -145,8 +151,8 @@ def main():
             'words_per_s': world * args.steps * words / elapsed,
             'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'launches': dom['launches'],
                          'avg_ms': dom['total_ms'] / dom['launches'], 'achieved': achieved,
-                         'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-                         'executed_tflops': executed, 'executed_frac': executed / F32_MFMA_PEAK_TFLOPS,
+                         'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                         'executed_tflops': executed, 'executed_frac': executed / peak,
                          'algorithm': ('Winograd F(2x2,3x3): `achieved` counts the direct convolution\'s flops, the matrix '
                                        'cores execute 16/36 of them (`executed`)') if dom['name'].startswith('conv_wino')
                          else 'direct implicit GEMM',

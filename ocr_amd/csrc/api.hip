@@ -23,6 +23,14 @@ static thread_local Profiler* g_prof = nullptr;
 Profiler* current_profiler() { return g_prof; }
 void set_current_profiler(Profiler* p) { g_prof = p; }
 
+static thread_local int g_compute_bf16 = 0;
+int compute_bf16() { return g_compute_bf16; }
+void set_compute_bf16(int on) { g_compute_bf16 = on; }
+// sets the bfloat16 switch for the duration of one API call
+struct Bf16Scope {
+    explicit Bf16Scope(int dtype) { set_compute_bf16(dtype == OCRHIP_BF16 ? 1 : 0); }
+    ~Bf16Scope() { set_compute_bf16(0); }
+};
 static thread_local int g_lstm_persistent = 1;
 int lstm_persistent() { return g_lstm_persistent; }
 void set_lstm_persistent(int on) { g_lstm_persistent = on; }
@@ -260,7 +268,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     if (!h) return OCRHIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.bias.release(); };
+    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.w_bf16.release(); L.bias.release(); };
     for (auto& L : h->crnn.rconv) free_layer(L);
     for (auto& L : h->east.vgg) free_layer(L);
     for (auto& L : h->east.merge) free_layer(L);
@@ -350,7 +358,8 @@ int ocrhip_east_forward(ocrhip_handle h, const void* d_img, int B, int H, int W,
     OCR_REQUIRE(d_img && d_maps, "east_forward: null buffer");
     OCR_REQUIRE(B > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, "east_forward: H and W must be positive multiples of 32 (B=%d H=%d W=%d)", B, H, W);
     OCR_REQUIRE(in_dtype == OCRHIP_U8 || in_dtype == OCRHIP_F32, "east_forward: in_dtype must be U8 or F32");
-    OCR_REQUIRE(compute_dtype == OCRHIP_F32, "east_forward: compute dtype %d not available in this build", compute_dtype);
+    OCR_REQUIRE(compute_dtype == OCRHIP_F32 || compute_dtype == OCRHIP_BF16, "east_forward: compute dtype %d is neither F32 nor BF16", compute_dtype);
+    Bf16Scope bf16_scope(compute_dtype);
     hipStream_t s = (hipStream_t)stream;
     const size_t px = (size_t)B * H * W;
     OCR_TRY(net.act[0].reserve(px * 64 * sizeof(float)));
@@ -685,7 +694,8 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
         return OCRHIP_ESTATE;
     }
     OCR_REQUIRE(d_crops && n > 0 && Wpad >= 8 && Wpad % 4 == 0, "crnn_forward: bad arguments n=%d Wpad=%d", n, Wpad);
-    OCR_REQUIRE(compute_dtype == OCRHIP_F32, "crnn_forward: compute dtype %d not available in this build", compute_dtype);
+    OCR_REQUIRE(compute_dtype == OCRHIP_F32 || compute_dtype == OCRHIP_BF16, "crnn_forward: compute dtype %d is neither F32 nor BF16", compute_dtype);
+    Bf16Scope bf16_scope(compute_dtype);
     OCR_REQUIRE(d_logits || d_tokens, "crnn_forward: ask for logits and/or tokens");
     OCR_REQUIRE(!d_tokens || d_scores, "crnn_forward: d_scores is required with d_tokens");
     hipStream_t s = (hipStream_t)stream;
@@ -718,7 +728,8 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
         return OCRHIP_ESTATE;
     }
     OCR_REQUIRE(d_packed && out_w && n > 0, "crnn_forward_packed: bad arguments n=%d", n);
-    OCR_REQUIRE(compute_dtype == OCRHIP_F32, "crnn_forward_packed: compute dtype %d not available in this build", compute_dtype);
+    OCR_REQUIRE(compute_dtype == OCRHIP_F32 || compute_dtype == OCRHIP_BF16, "crnn_forward_packed: compute dtype %d is neither F32 nor BF16", compute_dtype);
+    Bf16Scope bf16_scope(compute_dtype);
     OCR_REQUIRE(d_logits || d_tokens, "crnn_forward_packed: ask for logits and/or tokens");
     OCR_REQUIRE(!d_tokens || d_scores, "crnn_forward_packed: d_scores is required with d_tokens");
     hipStream_t s = (hipStream_t)stream;

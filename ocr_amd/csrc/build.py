@@ -32,6 +32,7 @@ SOURCES = {
     'conv_direct.hip': [],
     'conv_mfma.hip': [],
     'conv_wino.hip': ['-fno-slp-vectorize'],
+    'conv_bf16.hip': [],
     'rnn.hip': [],
     'rnn_persistent.hip': [],
     'pool.hip': [],

@@ -92,6 +92,7 @@ struct ConvLayer {
     int cin = 0, cout = 0, ks = 0;
     int cout_pad = 0;       // cout rounded up to the kernel's N tile
     DevBuf w_f32;           // MFMA slab layout (see conv_mfma.hip) or direct layout (see conv_direct.hip)
+    DevBuf w_bf16;          // bfloat16 slab of the same layer (see conv_bf16.hip), when cin % 16 == 0
     DevBuf w_wino;          // 3x3 layers with >= 64 output channels: Winograd-transformed filters (see conv_wino.hip)
     DevBuf bias;            // cout_pad floats, folded
     bool direct = false;    // small-Cin direct kernel layout
@@ -162,6 +163,14 @@ int prepare_conv_mfma(ConvLayer& L, const float* w_oihw, const float* bias, int 
 //   residual != nullptr (unpooled ks 3 / 2 only): a tensor shaped like y, added before the ReLU.
 int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
                      const float* up_src, int up_c, hipStream_t s, const float* residual = nullptr);
+
+// conv_bf16.hip: the same layers with bfloat16 operands (float32 accumulation and tensors); launch_conv_mfma forwards to
+// it while compute_bf16() is set (an API call with compute_dtype = OCRHIP_BF16 sets it for its duration).
+int prepare_conv_bf16(ConvLayer& L, const float* w_oihw, int cout, int cin, int ks);
+int launch_conv_bf16(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
+                     const float* up_src, int up_c, hipStream_t s, const float* residual);
+int compute_bf16();
+void set_compute_bf16(int on);
 
 // conv_wino.hip: the same 3x3 layers by Winograd F(2x2,3x3) (cout_pad % 64 == 0, cin % 8 == 0); launch_conv_mfma
 // forwards to it when the handle's "conv3x3_winograd" option is on (the default).

@@ -21,8 +21,9 @@ from .utils.text import CharTokenizer
 
 class OcrPipeline:
     def __init__(self, east_params, crnn_params, device=0, tokenizer=None, obj_threshold=0.35, nms_threshold=0.2,
-                 merge_threshold=0.3, merge_method='union', max_crop_elems=1 << 20, ctx=None):
+                 merge_threshold=0.3, merge_method='union', max_crop_elems=1 << 20, ctx=None, compute_dtype=F32):
         self.ctx = ctx or HipContext(device)
+        self.compute_dtype = compute_dtype          # F32 (the reference's precision) or BF16 operands with float32 accumulation
         self.device = self.ctx.device
         if east_params is not None:
             self.ctx.east_load_weights(east_params)
@@ -42,7 +43,7 @@ class OcrPipeline:
         `maps_override` replaces the network output as the input of decode (used with synthetic
         "teacher" maps when no trained detector weights exist); the network still runs."""
         B, H, W, _ = images.shape
-        maps = self.ctx.east_forward(images)
+        maps = self.ctx.east_forward(images, compute_dtype=self.compute_dtype)
         used = maps if maps_override is None else maps_override
         dec = self.ctx.east_decode(used, (H, W), self.obj_threshold)
         kept = self.ctx.lanms(dec['xyxy'], dec['scores'], dec['counts'], merge_threshold=self.merge_threshold,
@@ -101,7 +102,7 @@ class OcrPipeline:
         d_rects, d_inter = meta[:4 * n].view(n, 4), meta[4 * n:6 * n].view(n, 2)
         d_out_w, d_box_img = meta[6 * n:7 * n], meta[7 * n:8 * n]
         packed = self.ctx.crop_resize_pack(images, d_rects, d_box_img, d_inter, d_out_w, d_off, int(off[-1]))
-        out = self.ctx.crnn_forward_packed(packed, out_w)
+        out = self.ctx.crnn_forward_packed(packed, out_w, compute_dtype=self.compute_dtype)
         h_tokens = torch.empty(out['tokens'].shape, dtype=torch.int32, pin_memory=True)
         h_scores = torch.empty(out['scores'].shape, dtype=torch.float32, pin_memory=True)
         h_tokens.copy_(out['tokens'], non_blocking=True)

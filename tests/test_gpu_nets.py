@@ -184,3 +184,34 @@ def test_lstm_per_step_launches_match_the_persistent_layer(ctx):
     la, lb = a['logits'].cpu().numpy(), b['logits'].cpu().numpy()
     _close(la, lb, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(lb).max())))
     np.testing.assert_array_equal(a['lengths'].cpu().numpy(), b['lengths'].cpu().numpy())
+
+
+def test_bf16_variant_within_1e2_of_the_float32_oracle(ctx):
+    """`compute_dtype = BF16`: bfloat16 operands, float32 accumulation.  Tolerance: relative error of the whole tensor
+    ||got - ref|| / ||ref|| <= 1e-2 against the float32 oracle, and no single element further than 5e-2 of the tensor's
+    scale (20 layers of 2^-9 operand rounding under random weights leave a few 1e-2 outliers); the float32 path is held
+    to 1e-4 element-wise by the other tests."""
+    def rel(a, b):
+        return float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    from ocr_amd._lib import BF16
+    params = nets.init_east_params(seed=1)
+    ctx.east_load_weights(params)
+    rng = np.random.default_rng(123)
+    img = rng.integers(0, 256, (2, 96, 160, 3), dtype=np.uint8)
+    ref = nets.east_forward(params, np.stack([oimg.prepare_east_input(i) for i in img])).numpy()
+    got = ctx.east_forward(torch.from_numpy(img).cuda(), compute_dtype=BF16).cpu().numpy()
+    f32 = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
+    assert rel(got, ref) <= 1e-2 and np.abs(got - ref).max() <= 5e-2, (rel(got, ref), np.abs(got - ref).max())
+    assert np.abs(got - f32).max() > 0                                            # it really is another arithmetic
+    cp = nets.init_crnn_params(vocab_size=97, seed=2)
+    ctx.crnn_load_weights(cp)
+    x = rng.uniform(-1, 1, (4, 64, 160, 1)).astype(np.float32)
+    cref = nets.crnn_forward(cp, x).numpy()
+    cgot = ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True, compute_dtype=BF16)['logits'].cpu().numpy()
+    scale = float(np.abs(cref).max())
+    assert rel(cgot, cref) <= 1e-2 and np.abs(cgot - cref).max() <= 5e-2 * max(1.0, scale), (rel(cgot, cref), np.abs(cgot - cref).max(), scale)
+    widths = np.array([64, 64, 128, 160], dtype=np.int32)
+    packed = torch.from_numpy(rng.uniform(-1, 1, int(64 * widths.sum())).astype(np.float32)).cuda()
+    a = ctx.crnn_forward_packed(packed, widths, want_logits=True, compute_dtype=BF16)['logits'].cpu().numpy()
+    b = ctx.crnn_forward_packed(packed, widths, want_logits=True)['logits'].cpu().numpy()
+    assert rel(a, b) <= 1e-2, rel(a, b)

@@ -20,18 +20,21 @@ ap.add_argument('--crops', type=int, default=1024)
 ap.add_argument('--wpad', type=int, default=192)
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--backbone', default='vgg', choices=['vgg', 'resnet'])
+ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
 args = ap.parse_args()
 
+from ocr_amd._lib import BF16, F32  # noqa: E402
+DT = BF16 if args.dtype == 'bf16' else F32
 ctx = HipContext(0)
 ctx.east_load_weights(random_east_params(1))
 ctx.crnn_load_weights(random_crnn_params(97, seed=2, backbone=args.backbone))
 img = torch.randint(0, 256, (args.batch, args.size, args.size, 3), dtype=torch.uint8, device='cuda')
 crops = torch.rand((args.crops, 64, args.wpad), device='cuda') * 2 - 1
-ctx.east_forward(img)
-ctx.crnn_forward(crops, want_logits=False, want_tokens=True)
+ctx.east_forward(img, compute_dtype=DT)
+ctx.crnn_forward(crops, want_logits=False, want_tokens=True, compute_dtype=DT)
 torch.cuda.synchronize()
-for name, fn in (('east', lambda: ctx.east_forward(img)),
-                 ('crnn', lambda: ctx.crnn_forward(crops, want_logits=False, want_tokens=True))):
+for name, fn in (('east', lambda: ctx.east_forward(img, compute_dtype=DT)),
+                 ('crnn', lambda: ctx.crnn_forward(crops, want_logits=False, want_tokens=True, compute_dtype=DT))):
     ctx.profile_enable(True)
     for _ in range(args.reps):
         fn()
