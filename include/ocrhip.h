@@ -95,7 +95,8 @@ int ocrhip_image_resize_norm(ocrhip_handle h, const void* d_img, int in_dtype, i
  *   d_img : device, (B,H,W,3) NHWC, uint8 raw pixels or float32 already normalised; H, W % 32 == 0
  *   d_maps: device, (B,H/4,W/4,6) float32 = [score, d_top, d_bottom, d_left, d_right, angle],
  *           sigmoid outputs exactly as the Keras model returns them
- *   compute_dtype: OCRHIP_F32 (f32 MFMA, exact float32 products) or OCRHIP_BF16 */
+ *   compute_dtype: OCRHIP_F32 (float32 products and sums, the reference's precision) or OCRHIP_BF16 (operands of
+ *           the MFMA convolutions rounded to bfloat16, float32 accumulation and tensors; within 1e-2 of float32) */
 int ocrhip_east_forward(ocrhip_handle h, const void* d_img, int B, int H, int W, int in_dtype,
                         int compute_dtype, float* d_maps, ocrhip_stream stream);
 
