@@ -49,7 +49,9 @@ def test_east_forward_matches_oracle(ctx, B, H, W):
         _close(maps.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize('n,Wpad,V', [(3, 128, 97), (2, 64, 97), (33, 192, 211), (5, 208, 97), (1, 48, 97), (2, 1040, 97)])
+# V = 6719 is the simplified-Chinese head, len(zh_sim_g2 characters) + 1 (crnn_arch.py:153-160)
+@pytest.mark.parametrize('n,Wpad,V', [(3, 128, 97), (2, 64, 97), (33, 192, 211), (5, 208, 97), (1, 48, 97), (2, 1040, 97),
+                                      (3, 128, 6719)])
 def test_crnn_forward_matches_oracle(ctx, n, Wpad, V):
     params = nets.init_crnn_params(vocab_size=V, seed=2)
     ctx.crnn_load_weights(params)
