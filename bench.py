@@ -165,6 +165,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(images, maps, east_params, crnn_params, min(args.cpu_pages, B))
         print(json.dumps(line), flush=True)
+    pipe.ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -65,7 +65,7 @@ int ocrhip_destroy(ocrhip_handle h);
  *   "conv3x3_winograd": 1 (default) computes the 3x3 convolutions with >= 64 output channels by Winograd
  *   F(2x2,3x3) in float32 (2.25x fewer multiplications, results within float32 rounding of the direct sum);
  *   0 computes them as a direct implicit GEMM (a float32 fma chain over the taps and channels).
- *   "lstm_persistent": 1 (default) runs the recurrence of a BiLSTM layer as one persistent cooperative launch
+ *   "lstm_persistent": 1 (default) runs the recurrence of a BiLSTM layer as one launch of persistent workgroups
  *   (W_hh resident in LDS, h_t handed over through L2); 0 launches one kernel per time step.  Same arithmetic. */
 int ocrhip_set_option(ocrhip_handle h, const char* name, int value);
 

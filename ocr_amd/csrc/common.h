@@ -215,7 +215,7 @@ int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, c
                      float* h_next, float* c_state, float* out, int n, int T, int step, const int* seq_T,
                      const int* seq_row0, int first, hipStream_t s);
 
-// rnn_persistent.hip: a whole bidirectional layer in one cooperative launch (hbuf: 2 parities x 2 directions x n x 256,
+// rnn_persistent.hip: a whole bidirectional layer in one launch of persistent workgroups (hbuf: 2 parities x 2 directions x n x 256,
 // counters: 32 unsigned ints).  OCRHIP_ESTATE when the device cannot hold the grid at once (use the per-step kernel).
 int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, float* hbuf, float* cbuf,
                       float* out, int n, int T, const int* seq_T, const int* seq_row0, const int* step_active,

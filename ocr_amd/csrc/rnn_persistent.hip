@@ -16,15 +16,13 @@
 // of one wave, exchanged by a lane permute.  The 8 workgroups that share (direction, g) hand h_t to each other
 // through global memory: h is stored and loaded with agent-scope atomic accesses and one atomic counter per
 // (direction, g) says when a step is complete.
-// Nothing else synchronises; a group whose sequences are all finished leaves.  The launch is cooperative, which
-// makes the runtime verify that all workgroups are resident at once (the hand-over needs that); the spin on the
-// counter is bounded so that a lost partner can never hang the device: the wait gives up after ~1 s and the
+// Nothing else synchronises; a group whose sequences are all finished leaves.  The grid never exceeds what the device
+// holds at once (occupancy x CUs, checked by the launcher: the hand-over needs every workgroup resident); the spin
+// on the counter is bounded so that a lost partner can never hang the device: the wait gives up after ~1 s and the
 // workgroup runs on with whatever it finds.
 //
 // Bound: latency of the per-step hand-over for short batches, f32 MFMA rate for large ones
 // (2 * 2 * n_active * 1024 * 256 flop per step).
-#include <hip/hip_cooperative_groups.h>
-
 #include "common.h"
 
 namespace ocrhip {
@@ -288,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
 
 }  // namespace
 
-// One bidirectional LSTM layer over n sequences in one cooperative launch.  `counters` must hold 2 * 16 unsigned
+// One bidirectional LSTM layer over n sequences in one launch of persistent workgroups.  `counters` must hold 2 * 16 unsigned
 // ints (they are cleared here).  Returns OCRHIP_ESTATE when the device cannot hold the grid at once; the caller then
 // uses the per-step kernel.
 int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, float* hbuf, float* cbuf,
@@ -309,10 +307,10 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
         int per_cu = 0;
         OCR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_layer_kernel), 256, kLdsBytes));
         const int resident = per_cu * prop.multiProcessorCount;
-        mg = (prop.cooperativeLaunch && resident >= 16) ? std::min(16, resident / 16) : -1;
+        mg = (resident >= 16) ? std::min(16, resident / 16) : -1;
     }
     if (mg < 0) {
-        set_error("lstm_layer: the device cannot hold a cooperative grid");
+        set_error("lstm_layer: the device cannot hold the persistent grid at once");
         return OCRHIP_ESTATE;
     }
     LayerArgs a;
@@ -321,9 +319,10 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
     a.counters = counters; a.n = n; a.T = T;
     a.G = std::max(1, std::min(mg, (n + 15) / 16));          // no more groups than 16-row tiles of work
     OCR_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * 16 * sizeof(unsigned), s));
-    void* params[] = {&a};
-    OCR_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_layer_kernel), dim3(16 * a.G), dim3(256), params,
-                                             kLdsBytes, s));
+    // a plain launch: the grid is sized to what the device holds at once (checked above), which is all the hand-over
+    // needs; the cooperative-launch entry point, which performs the same check, crashes the profiler at process exit
+    hipLaunchKernelGGL(lstm_layer_kernel, dim3(16 * a.G), dim3(256), kLdsBytes, s, a);
+    OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }
 
