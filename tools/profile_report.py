@@ -32,7 +32,7 @@ def main(d):
     print('| kernel | launches | mean us | share of GPU time | HBM traffic / launch (PMC) | achieved GB/s | of 8 TB/s | MFMA busy | clock GHz |')
     print('|---|---|---|---|---|---|---|---|---|')
     for k, (n, ns) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
-        if ns / total < 2e-4:
+        if ns / total < 1e-5:
             continue
         t = traffic.get(k)
         m = mfma.get(k)
