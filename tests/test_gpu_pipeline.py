@@ -44,3 +44,31 @@ def test_pipeline_matches_cpu_reference_path():
     x = np.stack([__import__('oracle.image', fromlist=['x']).prepare_east_input(images[0])])
     ref_maps = nets.east_forward(east_params, x).numpy()
     np.testing.assert_allclose(maps_gpu.cpu().numpy(), ref_maps, rtol=1e-4, atol=1e-5)
+
+
+def test_blank_pages_and_streaming_batches():
+    """A page without any detection next to a page with text, a batch of blank pages only, and the software-pipelined
+    stream of batches: same results as one call per batch (base_ocr.py:182-184 skips what has no crop)."""
+    from ocr_amd import synth
+    from ocr_amd.pipeline import OcrPipeline
+    from ocr_amd.weights import random_crnn_params, random_east_params
+
+    pipe = OcrPipeline(random_east_params(3), random_crnn_params(97, seed=4))
+    images, maps, _ = synth.make_pages(9, 3, 256, 384, 16)
+    maps = maps.copy()
+    maps[1, ..., 0] = 0.01                                   # page 1: nothing above the score threshold
+    d_img, d_maps = torch.from_numpy(images).cuda(), torch.from_numpy(maps).cuda()
+    got = pipe(d_img, maps_override=d_maps)
+    assert len(got) == 3 and len(got[1]['boxes']) == 0 and got[1]['texts'] == [] and len(got[0]['boxes']) >= 5
+    blank = pipe(d_img[1:2], maps_override=d_maps[1:2])
+    assert len(blank) == 1 and len(blank[0]['boxes']) == 0
+    # streaming: 4 batches through run_batches == the same batches one by one
+    batches = [(d_img[i:i + 2], d_maps[i:i + 2]) for i in (0, 1, 0, 1)]
+    streamed = list(pipe.run_batches(iter(batches)))
+    assert len(streamed) == 4
+    for (im, mp), out in zip(batches, streamed):
+        single = pipe(im, maps_override=mp)
+        for a, b in zip(out, single):
+            np.testing.assert_array_equal(a['boxes'], b['boxes'])
+            assert a['texts'] == b['texts']
+            np.testing.assert_array_equal(a['scores'], b['scores'])
