@@ -47,6 +47,8 @@ struct WinoArgs {
     float* y;
     int B, H, W, cin, cout, relu;
     int tiles_x, tiles_per_image, n_blocks_n;
+    int vP, vB;            // vP > 0: the vB images of the batch lie side by side, vP columns apart (zeros between), and
+                           // the tiles cover that one wide image; B is 1 then and W stays the width of one image
 };
 
 constexpr int kUFloats = 16 * 64 * kUS;       // one U buffer: 48 KB
@@ -100,9 +102,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoArgs a)
     for (int i = 0; i < 3; ++i) {
         const int f = tid + i * 256;
         const int px = f >> 1, c4 = f & 1;
-        const int gy = y0 - 1 + px / kRawW, gx = x0 - 1 + px % kRawW;
-        raw_ok[i] = f < kRawPx * 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        raw_src[i] = raw_ok[i] ? ((((int64_t)b * a.H + gy) * a.W + gx) * a.cin + c4 * 4) : (int64_t)b * a.H * a.W * a.cin;
+        const int gy = y0 - 1 + px / kRawW;
+        int gx = x0 - 1 + px % kRawW, gb = b;
+        bool in_x = gx >= 0;
+        if (a.vP > 0 && in_x) {
+            gb = gx / a.vP;
+            gx -= gb * a.vP;
+            in_x = gb < a.vB;
+        }
+        raw_ok[i] = f < kRawPx * 2 && gy >= 0 && gy < a.H && in_x && gx < a.W;
+        raw_src[i] = raw_ok[i] ? ((((int64_t)gb * a.H + gy) * a.W + gx) * a.cin + c4 * 4) : (int64_t)b * a.H * a.W * a.cin;
         raw_dst[i] = (f < kRawPx * 2) ? (px * kRS + c4 * 4) : -1;
     }
     auto load_raw = [&](int kc) {
@@ -314,11 +323,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoArgs a)
     const bool vec_ok = (a.cout & 3) == 0 && co0 + 3 < a.cout;
 #pragma unroll 4
     for (int px = tid >> 4; px < kOutPx; px += 16) {
-        const int yy = oy0 + px / kOutW, xx = ox0 + px % kOutW;
+        const int yy = oy0 + px / kOutW;
+        int xx = ox0 + px % kOutW, ob = b;
+        if (a.vP > 0) {
+            const int po = (POOL == 1) ? (a.vP >> 1) : a.vP;      // period of the images in output columns
+            ob = xx / po;
+            xx -= ob * po;
+            if (ob >= a.vB) continue;
+        }
         if (yy >= Ho || xx >= Wo) continue;
         float4 val = *reinterpret_cast<const float4*>(&O[px * kOS + c4 * 4]);
         val.x += bias4.x; val.y += bias4.y; val.z += bias4.z; val.w += bias4.w;
-        const int64_t idx = (((int64_t)b * Ho + yy) * Wo + xx) * a.cout + co0;
+        const int64_t idx = (((int64_t)ob * Ho + yy) * Wo + xx) * a.cout + co0;
         if (vec_ok) {
             if (POOL == 0 && a.res) {
                 const float4 rr = *reinterpret_cast<const float4*>(a.res + idx);
@@ -385,9 +401,22 @@ int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H,
     a.x = x; a.w = L.w_wino.as<float>(); a.bias = L.bias.as<float>(); a.res = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.cin = L.cin; a.cout = L.cout; a.relu = relu ? 1 : 0;
     a.tiles_x = (W + 31) / 32;
+    a.vP = 0; a.vB = B;
+    // A batch of narrow images whose width leaves the 32-column tiles partly empty is laid side by side as one wide
+    // image, one zero column apart (two where the columns are pooled in pairs, so every image starts on an even
+    // column): the gap is the zero padding of both neighbours, and the tiles of the wide image are full.
+    if (B > 1 && W % 32 != 0) {
+        const int period = W + (pool == 1 ? 2 : 1);
+        const int64_t vw = (int64_t)B * period;
+        if (vw < (1ll << 30) && (vw + 31) / 32 < (int64_t)a.tiles_x * B) {
+            a.vP = period;
+            a.B = 1;
+            a.tiles_x = (int)((vw + 31) / 32);
+        }
+    }
     a.tiles_per_image = a.tiles_x * ((H + 7) / 8);
     a.n_blocks_n = L.cout_pad / 64;
-    const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
+    const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * a.B;
     OCR_REQUIRE(wgs < (1ll << 31), "conv_wino: too many workgroups");
     char pname[64];
     std::snprintf(pname, sizeof(pname), "conv_wino_f32<n64,pool%d,tile8x32>", pool);
