@@ -11,21 +11,23 @@
 // 2.25x fewer flops than the direct convolution performs.  The filter transform is done once at load time
 // (in double, rounded to float32); the data transform only adds and subtracts.
 //
-// Tiling (one workgroup = 4 waves, one workgroup per CU):
-//   spatial tile 8 rows x 32 columns of outputs = 4 x 16 blocks of 2x2, times 64 output channels;
-//   the 16 Winograd components are 16 independent GEMMs (blocks x Cin) x (Cin x Cout); a wave owns all 16
-//   components of 32 blocks x 32 channels: 16 accumulators of 32x32 (256 accumulator registers per lane), so the
-//   inverse transform needs no exchange: a lane holds the 16 components of its (block, channel) pairs.
-//   K: chunks of 8 input channels.  Per chunk the raw input tile with its halo (10 x 34 pixels) is staged in
-//   LDS, transformed into U[component][block][channel] in LDS (conflict-free 16-byte reads, block stride 12
-//   floats), and each lane loads its transformed-filter fragments straight from the lane-linear weight slab
-//   (16 coalesced 16-byte loads per chunk).  U and the raw tile are double buffered (128 KB of LDS) so the
-//   transform of the next chunk and all its loads are issued between the MFMAs of the current one.
+// Tiling (one workgroup = 4 waves, two workgroups per CU): 4 rows x 32 columns of outputs = 2 x 16 blocks of 2x2,
+// times 64 output channels.  The 16 Winograd components are 16 independent GEMMs (blocks x Cin) x (Cin x Cout).
+//   wave = (fh, ch): components 8 fh .. 8 fh + 7 (rows 2 fh, 2 fh + 1 of the 4x4 component matrix) of 32 blocks x
+//   channels 32 ch .. 32 ch + 31 = 8 accumulators of 32x32 = 128 registers per lane, so two waves fit on a SIMD and
+//   a workgroup needs under 80 KB of LDS: while one wave waits (barrier, loads, prologue, epilogue) the wave of the
+//   other workgroup on the same SIMD issues MFMAs.  (A lone wave per SIMD with all 16 components and every other
+//   instruction hand-placed between its MFMAs was measured 8 % slower.)
+//   K: chunks of 8 input channels.  Per chunk the raw input tile with its halo (6 x 34 pixels) is staged in LDS,
+//   transformed into U[component][block][channel] in LDS (conflict-free 16-byte reads, block stride 12 floats), and
+//   each lane loads its transformed-filter fragments straight from the lane-linear weight slab (8 coalesced 16-byte
+//   loads per chunk).  U and the raw tile are double buffered; one barrier per chunk.
+//   Epilogue: each wave applies the column half of the inverse transform to its two component rows, the two waves of
+//   a channel half leave their partial sums of the output rows in two LDS staging areas, and the output pass adds them
+//   (plus bias, residual, ReLU, optional max-pool) and writes 16-byte stores.
 //
 // Roofline: MFMA bound; the unit of work is the direct convolution's 2*9*Cin*Cout flop per output pixel, of
 // which 16/36 are executed.
-#include <type_traits>
-
 #include "common.h"
 
 namespace ocrhip {
@@ -37,7 +39,16 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int kCK = 8;            // input channels per chunk
 constexpr int kRS = 12;           // floats per raw pixel in LDS (8 + pad: conflict-free 16-byte reads)
 constexpr int kUS = 12;           // floats per (component, block) row of U
-constexpr int kRawW = 34, kRawH = 10, kRawPx = kRawW * kRawH;
+constexpr int kRawW = 34, kRawH = 6, kRawPx = kRawW * kRawH;
+constexpr int kBlocks = 32;       // 2 block rows x 16 block columns
+constexpr int kUC = kBlocks * kUS;            // floats per component of U
+constexpr int kUFloats = 16 * kUC;            // one U buffer: 24 KB
+constexpr int kRFloats = kRawPx * kRS;        // one raw-tile buffer: 9.6 KB
+constexpr int kOS = 68;                       // floats per staged output pixel (64 channels + pad)
+constexpr int kStage = 128 * kOS;             // one staging area of the epilogue: 4 x 32 pixels
+constexpr int kLoopFloats = 2 * kUFloats + 2 * kRFloats + 4;
+constexpr int kLdsFloats = kLoopFloats > 2 * kStage ? kLoopFloats : 2 * kStage;
+constexpr int kLdsBytes = kLdsFloats * 4;
 
 struct WinoArgs {
     const float* x;        // (B,H,W,cin)
@@ -51,55 +62,48 @@ struct WinoArgs {
                            // the tiles cover that one wide image; B is 1 then and W stays the width of one image
 };
 
-constexpr int kUFloats = 16 * 64 * kUS;       // one U buffer: 48 KB
-constexpr int kRFloats = kRawPx * kRS;        // one raw-tile buffer: 16 KB
-constexpr int kLdsBytes = (2 * kUFloats + 2 * kRFloats + 4) * 4;
-
 template <int POOL>
-__global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // U[2] then raw[2]: chunk j lives in buffer j & 1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int th = wave & 1;          // which 2 of the 4 block rows
+    const int fh = wave & 1;          // which 8 of the 16 components
     const int ch = wave >> 1;         // which 32 of the 64 output channels
 
-    // Workgroups go to the 8 XCDs round-robin; the work index is permuted so that every XCD walks a contiguous range of
-    // it with the channel block varying fastest: the channel blocks of one spatial tile run on the same XCD at about the
-    // same time and share the input tile through its L2 (measured: same speed as channel-block-major order, which keeps
-    // the filters in L2 instead, and 1.2x less memory-side traffic).
+    // Workgroups go to the 8 XCDs round-robin; the work index is permuted so that every XCD walks a contiguous range
+    // of it with the channel block varying fastest: the channel blocks of one spatial tile run on the same XCD at
+    // about the same time and share the input tile through its L2.
     const unsigned total = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const unsigned work = xcd * (total >> 3) + min(xcd, total & 7u) + slot;
     const int nb = (int)(work % (unsigned)a.n_blocks_n);
     const int tile_all = (int)(work / (unsigned)a.n_blocks_n);
     const int b = tile_all / a.tiles_per_image;
     const int tile = tile_all % a.tiles_per_image;
-    const int y0 = (tile / a.tiles_x) * 8, x0 = (tile % a.tiles_x) * 32;
+    const int y0 = (tile / a.tiles_x) * 4, x0 = (tile % a.tiles_x) * 32;
     const int nK = a.cin / kCK;
 
-    floatx16 acc[16];
+    floatx16 acc[8];
 #pragma unroll
-    for (int f = 0; f < 16; ++f)
+    for (int f = 0; f < 8; ++f)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[f][v] = 0.0f;
 
     // weight slab of this channel block: [k chunk][component][channel half][lane][4]
-    const float4* wslab = reinterpret_cast<const float4*>(a.w) + (int64_t)nb * nK * (16 * 2 * 64);
-    const float4* wlane = wslab + ch * 64 + lane;
+    const float4* wlane = reinterpret_cast<const float4*>(a.w) + (int64_t)nb * nK * (16 * 2 * 64) + (fh * 8) * 128 + ch * 64 + lane;
 
-    // raw tile: 340 pixels x 2 channel quads over 256 threads; addresses are fixed per thread
-    // All loads and stores are unconditional (pixels outside the image read the first pixel of the image and are
-    // replaced by zeros on the way to LDS; threads without a pixel store to a spare slot): the chunk loop stays one
-    // basic block, which keeps the compiler's count of outstanding loads exact.
-    float4 ra[3];
-    int64_t raw_src[3];
-    int raw_dst[3];
-    bool raw_ok[3];
+    // raw tile: 204 pixels x 2 channel quads over 256 threads, two per thread; addresses are fixed per thread.
+    // Loads and stores are unconditional (pixels outside the image read the first pixel of the image and are replaced
+    // by zeros on the way to LDS; threads without a pixel store to a spare slot).
+    float4 ra[2];
+    int64_t raw_src[2];
+    int raw_dst[2];
+    bool raw_ok[2];
     constexpr int kDummy = 2 * kUFloats + 2 * kRFloats;     // 16 spare bytes behind the buffers
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const int f = tid + i * 256;
         const int px = f >> 1, c4 = f & 1;
         const int gy = y0 - 1 + px / kRawW;
@@ -112,219 +116,176 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoArgs a)
         }
         raw_ok[i] = f < kRawPx * 2 && gy >= 0 && gy < a.H && in_x && gx < a.W;
         raw_src[i] = raw_ok[i] ? ((((int64_t)gb * a.H + gy) * a.W + gx) * a.cin + c4 * 4) : (int64_t)b * a.H * a.W * a.cin;
-        raw_dst[i] = (f < kRawPx * 2) ? (px * kRS + c4 * 4) : -1;
+        raw_dst[i] = (f < kRawPx * 2) ? (px * kRS + c4 * 4) : kDummy;
     }
     auto load_raw = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ra[i] = *reinterpret_cast<const float4*>(a.x + raw_src[i] + kc * kCK);
+        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(a.x + raw_src[i] + kc * kCK);
     };
-    auto store_raw_one = [&](int rbase, int i) {
-        const int idx = raw_dst[i] >= 0 ? rbase + raw_dst[i] : kDummy;
-        const float4 v = ra[i];
-        *reinterpret_cast<float4*>(&lds[idx]) = raw_ok[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto store_raw = [&](int rbase) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = raw_dst[i] == kDummy ? kDummy : rbase + raw_dst[i];
+            *reinterpret_cast<float4*>(&lds[idx]) = raw_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
 
-    // Data transform: a thread owns (block, 4 channels, 2 of the 4 component rows i), one row per pass `ii`:
+    // Data transform: a thread owns (block, 4 channels, component row i):
     //   i = 0: d0 - d2,  i = 1: d1 + d2,  i = 2: d2 - d1,  i = 3: d1 - d3     (rows of B^T d) = dA + sgn * dB,
     // then (.) B along the columns.
-    const int t_cq = tid & 1, t_tx = (tid >> 1) & 15, t_half = (tid >> 5) & 1, t_ty = tid >> 6;
+    const int t_cq = tid & 1, t_tx = (tid >> 1) & 15, t_i = (tid >> 5) & 3, t_ty = tid >> 7;
     const int t_src = ((2 * t_ty) * kRawW + 2 * t_tx) * kRS + t_cq * 4;
-    int t_offA[2], t_offB[2], t_dst[2];
-    float t_sgn[2];
+    const int rowA = (t_i == 0) ? 0 : (t_i == 2 ? 2 : 1);
+    const int rowB = (t_i == 0 || t_i == 1) ? 2 : (t_i == 2 ? 1 : 3);
+    const int t_offA = t_src + rowA * kRawW * kRS, t_offB = t_src + rowB * kRawW * kRS;
+    const float t_sgn = (t_i == 1) ? 1.0f : -1.0f;
+    const int t_dst = t_i * 4 * kUC + (t_ty * 16 + t_tx) * kUS + t_cq * 4;
+    auto transform = [&](int rbase, int ubase) {
+        float4 tt[4];
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-        const int i = t_half * 2 + ii;
-        const int rowA = (i == 0) ? 0 : (i == 2 ? 2 : 1);
-        const int rowB = (i == 0 || i == 1) ? 2 : (i == 2 ? 1 : 3);
-        t_offA[ii] = t_src + rowA * kRawW * kRS;
-        t_offB[ii] = t_src + rowB * kRawW * kRS;
-        t_sgn[ii] = (i == 1) ? 1.0f : -1.0f;
-        t_dst[ii] = i * 4 * 64 * kUS + (t_ty * 16 + t_tx) * kUS + t_cq * 4;
-    }
-    float4 trA[4], trB[4], tt[4], tu[4];       // transform registers: raw rows, B^T d row, finished components
-    auto tr_read = [&](int rbase, int ii, int c) {
-        trA[c] = *reinterpret_cast<const float4*>(&lds[rbase + t_offA[ii] + c * kRS]);
-        trB[c] = *reinterpret_cast<const float4*>(&lds[rbase + t_offB[ii] + c * kRS]);
-    };
-    // an empty volatile asm that "rewrites" a value: keeps the producer before it and the consumers behind it, which
-    // pins the slice of work to its slot (the instruction scheduler would otherwise hoist it next to its loads)
-    auto pin = [](float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
-    auto tr_row = [&](int ii, int c) {
-        pin(trA[c]);
-        pin(trB[c]);
-        const float sg = t_sgn[ii];
-        tt[c] = make_float4(fmaf(sg, trB[c].x, trA[c].x), fmaf(sg, trB[c].y, trA[c].y), fmaf(sg, trB[c].z, trA[c].z),
-                            fmaf(sg, trB[c].w, trA[c].w));
-    };
-    auto tr_col = [&](int j) {
-        pin(tt[j == 0 ? 0 : 1]);
-        pin(tt[j == 3 ? 3 : 2]);
-        if (j == 0) tu[0] = make_float4(tt[0].x - tt[2].x, tt[0].y - tt[2].y, tt[0].z - tt[2].z, tt[0].w - tt[2].w);
-        if (j == 1) tu[1] = make_float4(tt[1].x + tt[2].x, tt[1].y + tt[2].y, tt[1].z + tt[2].z, tt[1].w + tt[2].w);
-        if (j == 2) tu[2] = make_float4(tt[2].x - tt[1].x, tt[2].y - tt[1].y, tt[2].z - tt[1].z, tt[2].w - tt[1].w);
-        if (j == 3) tu[3] = make_float4(tt[1].x - tt[3].x, tt[1].y - tt[3].y, tt[1].z - tt[3].z, tt[1].w - tt[3].w);
-    };
-    auto tr_write = [&](int ubase, int ii, int j) {
-        *reinterpret_cast<float4*>(&lds[ubase + t_dst[ii] + j * 64 * kUS]) = tu[j];
+        for (int c = 0; c < 4; ++c) {
+            const float4 p = *reinterpret_cast<const float4*>(&lds[rbase + t_offA + c * kRS]);
+            const float4 q = *reinterpret_cast<const float4*>(&lds[rbase + t_offB + c * kRS]);
+            tt[c] = make_float4(fmaf(t_sgn, q.x, p.x), fmaf(t_sgn, q.y, p.y), fmaf(t_sgn, q.z, p.z), fmaf(t_sgn, q.w, p.w));
+        }
+        float* u = &lds[ubase + t_dst];
+        *reinterpret_cast<float4*>(u) = make_float4(tt[0].x - tt[2].x, tt[0].y - tt[2].y, tt[0].z - tt[2].z, tt[0].w - tt[2].w);
+        *reinterpret_cast<float4*>(u + kUC) = make_float4(tt[1].x + tt[2].x, tt[1].y + tt[2].y, tt[1].z + tt[2].z, tt[1].w + tt[2].w);
+        *reinterpret_cast<float4*>(u + 2 * kUC) = make_float4(tt[2].x - tt[1].x, tt[2].y - tt[1].y, tt[2].z - tt[1].z, tt[2].w - tt[1].w);
+        *reinterpret_cast<float4*>(u + 3 * kUC) = make_float4(tt[1].x - tt[3].x, tt[1].y - tt[3].y, tt[1].z - tt[3].z, tt[1].w - tt[3].w);
     };
 
-    float4 bw[16];
-    float4 af[2][8];                     // A fragments of the current and of the next half (8 components) of a chunk
-    const int u_src = (th * 32 + li) * kUS + lh * 4;
-    auto af_read = [&](int ubase, int half, int first, int set) {      // components 8 half + first .. + 3
+    float4 bw[8], af[2][4];              // filter fragments of a chunk; A fragments of the two groups of 4 components
+    const int u_src = (fh * 8) * kUC + li * kUS + lh * 4;
+    auto af_read = [&](int ubase, int g) {
 #pragma unroll
-        for (int i = first; i < first + 4; ++i)
-            af[set][i] = *reinterpret_cast<const float4*>(&lds[ubase + (half * 8 + i) * 64 * kUS + u_src]);
+        for (int i = 0; i < 4; ++i) af[g][i] = *reinterpret_cast<const float4*>(&lds[ubase + u_src + (g * 4 + i) * kUC]);
     };
 
-    // prologue: chunk 0 transformed into U[0], raw tile of chunk 1 in raw[1], filter fragments of chunk 0 in registers
+    // prologue: chunk 0 transformed into U[0], raw tile 1 in raw[1], raw tile 2 on its way to registers, filter
+    // fragments of chunk 0 and the A fragments of its first group in registers
     constexpr int kR0 = 2 * kUFloats, kR1 = 2 * kUFloats + kRFloats;
     load_raw(0);
 #pragma unroll
-    for (int f = 0; f < 8; ++f) bw[f] = wlane[f * 128];         // fragments 8..15 are loaded by the chunk itself
-#pragma unroll
-    for (int i = 0; i < 3; ++i) store_raw_one(kR0, i);
-    if (nK > 1) load_raw(1);
+    for (int f = 0; f < 8; ++f) bw[f] = wlane[f * 128];
+    store_raw(kR0);
+    load_raw(min(1, nK - 1));
     __syncthreads();
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) tr_read(kR0, ii, c);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) tr_row(ii, c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tr_col(j);
-            tr_write(0, ii, j);
-        }
-    }
-    if (nK > 1) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) store_raw_one(kR1, i);
-    }
+    transform(kR0, 0);
+    store_raw(kR1);
+    load_raw(min(2, nK - 1));
     __syncthreads();
-    af_read(0, 0, 0, 0);
-    af_read(0, 0, 4, 0);
-    // every load of the prologue has landed before the loop: the waits inside the loop are then derived from the
-    // loop's own loads only (a pending prologue load would make the wait at the loop head conservative for every trip)
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    af_read(0, 0);
 
-    // Chunk kc: 64 MFMAs on U[kc & 1] in 2 halves of 32 (8 components x 4 k steps; an accumulator is used again 8 MFMAs
-    // later: with only 4 in flight the dependent-accumulator latency caps a lone wave at 79 % of the MFMA rate).  All other
-    // work of the wave is sliced into the gaps between them, at most ~6 instructions per gap (a lone wave issues one
-    // instruction per 4 cycles; what does not fit into the 64 cycles of an MFMA delays the next one): the A fragments of
-    // the next half, the transform of chunk kc+1 (raw[(kc+1) & 1] -> U[(kc+1) & 1], rows 0 and 1 of this thread's pair),
-    // the filter fragments (components 8..15 of this chunk at its start, 0..7 of chunk kc+1 after their last use), the raw
-    // tile of chunk kc+2 (global -> registers -> raw[kc & 1]) and two barriers: slot 0 (raw tile kc+1 visible, U[(kc+1) & 1]
-    // no longer read) and slot 44 (U[(kc+1) & 1] complete, so the A fragments of its first half can be fetched early).
-    auto chunk = [&](int kc, auto more_c, auto more2_c) {
-        constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
+    // Chunk kc = 32 MFMAs in two groups of 4 components x 4 k steps, one barrier in the middle, no branches; everything
+    // a group needs was requested a group earlier.  On entry: U[kc & 1] complete, the A fragments of group 0 and the
+    // filter fragments of the chunk in registers, raw tile kc + 1 in raw[(kc + 1) & 1], raw tile kc + 2 in flight.
+    //   group 0: A fragments of group 1 requested; transform of chunk kc + 1 (raw[(kc + 1) & 1] -> U[(kc + 1) & 1]) between
+    //            the MFMAs; raw tile kc + 2 into raw[kc & 1]; filter fragments 0..3 reloaded for chunk kc + 1
+    //   barrier: U[(kc + 1) & 1] and raw tile kc + 2 visible; nobody reads U[kc & 1]... group 1 still does, from registers
+    //   group 1: A fragments of group 0 of chunk kc + 1 and raw tile kc + 3 requested; filter fragments 4..7 reloaded
+    // Past the end of K the same loads and stores run on the last chunk again and their results are not used.
+    for (int kc = 0; kc < nK; ++kc) {
         const int ucur = (kc & 1) * kUFloats, unxt = ((kc + 1) & 1) * kUFloats;
         const int rnxt = 2 * kUFloats + ((kc + 1) & 1) * kRFloats, rfill = 2 * kUFloats + (kc & 1) * kRFloats;
-        const float4* wcur = wlane + (int64_t)kc * (16 * 2 * 64);
-        const float4* wnext = wcur + 16 * 2 * 64;
+        const float4* wnext = wlane + (int64_t)min(kc + 1, nK - 1) * (16 * 2 * 64);
+        af_read(ucur, 1);
+        float4 tp[4], tq[4], tt[4];
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int c = 0; c < 4; ++c) {
+            tp[c] = *reinterpret_cast<const float4*>(&lds[rnxt + t_offA + c * kRS]);
+            tq[c] = *reinterpret_cast<const float4*>(&lds[rnxt + t_offB + c * kRS]);
+        }
+        float* u = &lds[unxt + t_dst];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int g = 0; g < 2; ++g) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int sl = half * 32 + t * 8 + i, f = half * 8 + i;
-            const float4 a4 = af[half][i], b4 = bw[f];
-            const float av = t == 0 ? a4.x : (t == 1 ? a4.y : (t == 2 ? a4.z : a4.w));
-            const float bv = t == 0 ? b4.x : (t == 1 ? b4.y : (t == 2 ? b4.z : b4.w));
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[f], 0, 0, 0);
-            // ---- side work of this gap
-            if (more && sl == 0) __syncthreads();
-            if (sl == 1) af_read(ucur, 1, 0, 1);
-            if (sl == 3) af_read(ucur, 1, 4, 1);
-            if (sl == 2 || sl == 4 || sl == 6 || sl == 8) {
-                const int q = 8 + (sl - 2);
-                bw[q] = wcur[q * 128];
-                bw[q + 1] = wcur[(q + 1) * 128];
-            }
-            if (more2 && sl == 11) load_raw(kc + 2);
-            if (more) {
-                if (sl == 5 || sl == 7) tr_read(rnxt, 0, (sl - 5) >> 1);
-                if (sl == 9 || sl == 10) tr_read(rnxt, 0, sl - 7);
-                if (sl >= 12 && sl <= 15) tr_row(0, sl - 12);
-                if (sl >= 17 && sl <= 20) { tr_col(sl - 17); tr_write(unxt, 0, sl - 17); }
-                if (sl >= 21 && sl <= 24) tr_read(rnxt, 1, sl - 21);
-                if (sl >= 26 && sl <= 29) tr_row(1, sl - 26);
-                if (sl == 31 || (sl >= 34 && sl <= 36)) { const int j = sl == 31 ? 0 : sl - 33; tr_col(j); tr_write(unxt, 1, j); }
-                if (sl >= 37 && sl <= 40) {
-                    const int q = 2 * (sl - 37);
-                    bw[q] = wnext[q * 128];
-                    bw[q + 1] = wnext[(q + 1) * 128];
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = g * 4 + i;
+                    const float4 a4 = af[g][i], b4 = bw[f];
+                    const float av = t == 0 ? a4.x : (t == 1 ? a4.y : (t == 2 ? a4.z : a4.w));
+                    const float bv = t == 0 ? b4.x : (t == 1 ? b4.y : (t == 2 ? b4.z : b4.w));
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[f], 0, 0, 0);
                 }
-                if (sl == 44) __syncthreads();
-                if (sl == 46) af_read(unxt, 0, 0, 0);
-                if (sl == 48) af_read(unxt, 0, 4, 0);
+                if (g == 0) {
+                    if (t < 2) {
+#pragma unroll
+                        for (int c = 2 * t; c < 2 * t + 2; ++c)
+                            tt[c] = make_float4(fmaf(t_sgn, tq[c].x, tp[c].x), fmaf(t_sgn, tq[c].y, tp[c].y), fmaf(t_sgn, tq[c].z, tp[c].z),
+                                                fmaf(t_sgn, tq[c].w, tp[c].w));
+                    }
+                    if (t == 2) {
+                        *reinterpret_cast<float4*>(u) = make_float4(tt[0].x - tt[2].x, tt[0].y - tt[2].y, tt[0].z - tt[2].z, tt[0].w - tt[2].w);
+                        *reinterpret_cast<float4*>(u + kUC) = make_float4(tt[1].x + tt[2].x, tt[1].y + tt[2].y, tt[1].z + tt[2].z, tt[1].w + tt[2].w);
+                    }
+                    if (t == 3) {
+                        *reinterpret_cast<float4*>(u + 2 * kUC) = make_float4(tt[2].x - tt[1].x, tt[2].y - tt[1].y, tt[2].z - tt[1].z, tt[2].w - tt[1].w);
+                        *reinterpret_cast<float4*>(u + 3 * kUC) = make_float4(tt[1].x - tt[3].x, tt[1].y - tt[3].y, tt[1].z - tt[3].z, tt[1].w - tt[3].w);
+                        store_raw(rfill);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (more2 && (sl == 50 || sl == 52 || sl == 54)) store_raw_one(rfill, (sl - 50) >> 1);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bw[g * 4 + i] = wnext[(g * 4 + i) * 128];
+            if (g == 0) {
+                __syncthreads();
+                af_read(unxt, 0);
+                load_raw(min(kc + 3, nK - 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-    };
-    {
-        int kc = 0;
-        for (; kc + 2 < nK; ++kc) chunk(kc, std::true_type{}, std::true_type{});
-        if (kc + 1 < nK) {
-            chunk(kc, std::true_type{}, std::false_type{});
-            ++kc;
-        }
-        chunk(kc, std::false_type{}, std::false_type{});
     }
 
-    // ---- inverse transform and optional pool in registers, then through LDS so that the tile leaves as 16-byte
-    // stores (4x fewer store instructions than one dword per lane; the store tail is issue bound).  Register v of a
-    // lane belongs to block m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5) of the wave's 32 (2 block rows x 16 block
-    // columns) and to output channel lane & 31 of the wave's 32.
-    constexpr int kOS = 68;                                    // floats per staged pixel (64 channels + pad)
-    constexpr int kOutW = (POOL == 1) ? 16 : 32;               // staged pixels per row
-    constexpr int kOutPx = (POOL == 0) ? 256 : (POOL == 1 ? 64 : 128);
+    // ---- inverse transform.  Register v of a lane belongs to block m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5) of the
+    // 32 (2 block rows x 16 block columns) and to output channel lane & 31 of the wave's 32.  With Z_i = (row i of the
+    // component matrix) A, the outputs are Y row 0 = Z0 + Z1 + Z2 and Y row 1 = Z1 - Z2 - Z3: the wave with rows 0, 1
+    // stages (Z0 + Z1, Z1), the wave with rows 2, 3 stages (Z2, -Z2 - Z3), and the output pass adds the two.
     __syncthreads();                                           // every wave is done with U
-    float* O = lds;
+    float* O = lds + fh * kStage;
     const int oc = ch * 32 + li;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int m = (v & 3) + 8 * (v >> 2) + 4 * lh;
-        const int ty = th * 2 + (m >> 4), tx = m & 15;
-        float s[2][4];       // A^T M : rows 0,1 x 4 columns
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[0][j] = acc[j][v] + acc[4 + j][v] + acc[8 + j][v];
-            s[1][j] = acc[4 + j][v] - acc[8 + j][v] - acc[12 + j][v];
-        }
-        float o[2][2];
+        const int ty = m >> 4, tx = m & 15;
+        float z[2][2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            o[r][0] = s[r][0] + s[r][1] + s[r][2];
-            o[r][1] = s[r][1] - s[r][2] - s[r][3];
+            z[r][0] = acc[4 * r][v] + acc[4 * r + 1][v] + acc[4 * r + 2][v];
+            z[r][1] = acc[4 * r + 1][v] - acc[4 * r + 2][v] - acc[4 * r + 3][v];
         }
-        if (POOL == 0) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) O[((2 * ty + r) * 32 + 2 * tx + c) * kOS + oc] = o[r][c];
-        } else if (POOL == 1) {
-            O[(ty * 16 + tx) * kOS + oc] = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
-        } else {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) O[(ty * 32 + 2 * tx + c) * kOS + oc] = fmaxf(o[0][c], o[1][c]);
+        for (int c = 0; c < 2; ++c) {
+            const float r0 = fh == 0 ? z[0][c] + z[1][c] : z[0][c];
+            const float r1 = fh == 0 ? z[1][c] : -z[0][c] - z[1][c];
+            O[((2 * ty) * 32 + 2 * tx + c) * kOS + oc] = r0;
+            O[((2 * ty + 1) * 32 + 2 * tx + c) * kOS + oc] = r1;
         }
     }
     __syncthreads();
-    // output pass: thread -> (pixel, 4 channels); bias, residual, ReLU here
+    // output pass: thread -> (pixel, 4 channels); sum of the two staging areas, max-pool, bias, residual, ReLU
+    constexpr int kOutW = (POOL == 1) ? 16 : 32;               // output pixels per tile row
+    constexpr int kOutPx = (POOL == 0) ? 128 : (POOL == 1 ? 32 : 64);
     const int c4 = tid & 15;
     const int co0 = nb * 64 + c4 * 4;
     const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + co0);          // bias is padded to cout_pad
     const int Ho = (POOL == 0) ? a.H : a.H / 2, Wo = (POOL == 1) ? a.W / 2 : a.W;
     const int oy0 = (POOL == 0) ? y0 : (y0 >> 1), ox0 = (POOL == 1) ? (x0 >> 1) : x0;
     const bool vec_ok = (a.cout & 3) == 0 && co0 + 3 < a.cout;
-#pragma unroll 4
+    auto staged = [&](int row, int col) {
+        const float4 p = *reinterpret_cast<const float4*>(&lds[(row * 32 + col) * kOS + c4 * 4]);
+        const float4 q = *reinterpret_cast<const float4*>(&lds[kStage + (row * 32 + col) * kOS + c4 * 4]);
+        return make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+    };
+    auto max4 = [](float4 p, float4 q) { return make_float4(fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), fmaxf(p.w, q.w)); };
+#pragma unroll 2
     for (int px = tid >> 4; px < kOutPx; px += 16) {
-        const int yy = oy0 + px / kOutW;
-        int xx = ox0 + px % kOutW, ob = b;
+        const int py = px / kOutW, pxx = px % kOutW;
+        const int yy = oy0 + py;
+        int xx = ox0 + pxx, ob = b;
         if (a.vP > 0) {
             const int po = (POOL == 1) ? (a.vP >> 1) : a.vP;      // period of the images in output columns
             ob = xx / po;
@@ -332,7 +293,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoArgs a)
             if (ob >= a.vB) continue;
         }
         if (yy >= Ho || xx >= Wo) continue;
-        float4 val = *reinterpret_cast<const float4*>(&O[px * kOS + c4 * 4]);
+        float4 val;
+        if (POOL == 0) val = staged(py, pxx);
+        else if (POOL == 1) val = max4(max4(staged(2 * py, 2 * pxx), staged(2 * py, 2 * pxx + 1)), max4(staged(2 * py + 1, 2 * pxx), staged(2 * py + 1, 2 * pxx + 1)));
+        else val = max4(staged(2 * py, pxx), staged(2 * py + 1, pxx));
         val.x += bias4.x; val.y += bias4.y; val.z += bias4.z; val.w += bias4.w;
         const int64_t idx = (((int64_t)ob * Ho + yy) * Wo + xx) * a.cout + co0;
         if (vec_ok) {
@@ -390,7 +354,7 @@ int prepare_conv_wino(ConvLayer& L, const float* w_oihw, int cout, int cin) {
 }
 
 int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
-                     const float* residual, hipStream_t s) {
+                      const float* residual, hipStream_t s) {
     OCR_REQUIRE(L.ks == 3 && L.w_wino.ptr, "conv_wino: layer has no transformed filters");
     OCR_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "conv_wino: bad arguments B=%d H=%d W=%d", B, H, W);
     OCR_REQUIRE(L.cout_pad % 64 == 0 && L.cin % kCK == 0, "conv_wino: layer shape %d -> %d not supported", L.cin, L.cout);
@@ -414,12 +378,12 @@ int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H,
             a.tiles_x = (int)((vw + 31) / 32);
         }
     }
-    a.tiles_per_image = a.tiles_x * ((H + 7) / 8);
+    a.tiles_per_image = a.tiles_x * ((H + 3) / 4);
     a.n_blocks_n = L.cout_pad / 64;
     const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * a.B;
     OCR_REQUIRE(wgs < (1ll << 31), "conv_wino: too many workgroups");
     char pname[64];
-    std::snprintf(pname, sizeof(pname), "conv_wino_f32<n64,pool%d,tile8x32>", pool);
+    std::snprintf(pname, sizeof(pname), "conv_wino_f32<n64,pool%d,tile4x32>", pool);
     const double out_px = (double)B * H * W;
     const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : (pool == 2 ? 2.0 : 1.0));
     ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,

@@ -24,7 +24,7 @@ def stage_name(kernel):
                                                                   m.group(4) == 'true', rows, cols)
     m = re.search(r'conv_wino_f32_kernel<(\d+)>', kernel)
     if m:
-        return 'conv_wino_f32<n64,pool%s,tile8x32>' % m.group(1)
+        return 'conv_wino_f32<n64,pool%s,tile4x32>' % m.group(1)
     m = re.search(r'(\w+)_kernel', kernel)
     if m:
         return m.group(1)
