@@ -44,11 +44,11 @@ constexpr int kBlocks = 32;       // 2 block rows x 16 block columns
 constexpr int kUC = kBlocks * kUS;            // floats per component of U
 constexpr int kUFloats = 16 * kUC;            // one U buffer: 24 KB
 constexpr int kRFloats = kRawPx * kRS;        // one raw-tile buffer: 9.6 KB
-constexpr int kOS = 68;                       // floats per staged output pixel (64 channels + pad)
-constexpr int kStage = 128 * kOS;             // one staging area of the epilogue: 4 x 32 pixels
 constexpr int kLoopFloats = 2 * kUFloats + 2 * kRFloats + 4;
-constexpr int kLdsFloats = kLoopFloats > 2 * kStage ? kLoopFloats : 2 * kStage;
-constexpr int kLdsBytes = kLdsFloats * 4;
+// CHB = channel blocks of 32 per workgroup (2 or 4); the epilogue stages 2 x 128 pixels x (32 CHB + 4) floats
+constexpr int lds_bytes(int chb) {
+    return 4 * (kLoopFloats > 2 * 128 * (32 * chb + 4) ? kLoopFloats : 2 * 128 * (32 * chb + 4));
+}
 
 struct WinoArgs {
     const float* x;        // (B,H,W,cin)
@@ -62,8 +62,12 @@ struct WinoArgs {
                            // the tiles cover that one wide image; B is 1 then and W stays the width of one image
 };
 
-template <int POOL>
-__global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a) {
+template <int POOL, int CHB>
+__global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_kernel(const WinoArgs a) {
+    constexpr int NT = 128 * CHB;               // threads: 2 CHB waves, two per SIMD either way
+    constexpr int NCH = 32 * CHB;               // output channels of the workgroup
+    constexpr int kOS = NCH + 4;                // floats per staged output pixel
+    constexpr int kStage = 128 * kOS;           // one staging area of the epilogue: 4 x 32 pixels
     extern __shared__ __attribute__((aligned(16))) float lds[];      // U[2] then raw[2]: chunk j lives in buffer j & 1
 
     const int tid = threadIdx.x;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int fh = wave & 1;          // which 8 of the 16 components
-    const int ch = wave >> 1;         // which 32 of the 64 output channels
+    const int ch = wave >> 1;         // which 32 of the NCH output channels
 
     // Workgroups go to the 8 XCDs round-robin; the work index is permuted so that every XCD walks a contiguous range
     // of it with the channel block varying fastest: the channel blocks of one spatial tile run on the same XCD at
@@ -91,20 +95,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[f][v] = 0.0f;
 
-    // weight slab of this channel block: [k chunk][component][channel half][lane][4]
-    const float4* wlane = reinterpret_cast<const float4*>(a.w) + (int64_t)nb * nK * (16 * 2 * 64) + (fh * 8) * 128 + ch * 64 + lane;
+    // weight slab of a block of 64 channels: [k chunk][component][channel half][lane][4]
+    const float4* wlane = reinterpret_cast<const float4*>(a.w) + (int64_t)(nb * (CHB / 2) + (ch >> 1)) * nK * (16 * 2 * 64) +
+                          (fh * 8) * 128 + (ch & 1) * 64 + lane;
 
-    // raw tile: 204 pixels x 2 channel quads over 256 threads, two per thread; addresses are fixed per thread.
+    // raw tile: 204 pixels x 2 channel quads over the threads (two or one per thread); addresses are fixed per thread.
     // Loads and stores are unconditional (pixels outside the image read the first pixel of the image and are replaced
     // by zeros on the way to LDS; threads without a pixel store to a spare slot).
-    float4 ra[2];
-    int64_t raw_src[2];
-    int raw_dst[2];
-    bool raw_ok[2];
+    constexpr int NRAW = (kRawPx * 2 + NT - 1) / NT;
+    float4 ra[NRAW];
+    int64_t raw_src[NRAW];
+    int raw_dst[NRAW];
+    bool raw_ok[NRAW];
     constexpr int kDummy = 2 * kUFloats + 2 * kRFloats;     // 16 spare bytes behind the buffers
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int f = tid + i * 256;
+    for (int i = 0; i < NRAW; ++i) {
+        const int f = tid + i * NT;
         const int px = f >> 1, c4 = f & 1;
         const int gy = y0 - 1 + px / kRawW;
         int gx = x0 - 1 + px % kRawW, gb = b;
@@ -120,11 +126,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a)
     }
     auto load_raw = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(a.x + raw_src[i] + kc * kCK);
+        for (int i = 0; i < NRAW; ++i) ra[i] = *reinterpret_cast<const float4*>(a.x + raw_src[i] + kc * kCK);
     };
     auto store_raw = [&](int rbase) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NRAW; ++i) {
             const int idx = raw_dst[i] == kDummy ? kDummy : rbase + raw_dst[i];
             *reinterpret_cast<float4*>(&lds[idx]) = raw_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -132,27 +138,57 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a)
 
     // Data transform: a thread owns (block, 4 channels, component row i):
     //   i = 0: d0 - d2,  i = 1: d1 + d2,  i = 2: d2 - d1,  i = 3: d1 - d3     (rows of B^T d) = dA + sgn * dB,
-    // then (.) B along the columns.
-    const int t_cq = tid & 1, t_tx = (tid >> 1) & 15, t_i = (tid >> 5) & 3, t_ty = tid >> 7;
-    const int t_src = ((2 * t_ty) * kRawW + 2 * t_tx) * kRS + t_cq * 4;
+    // then (.) B along the columns: components j = 0..3 = t0 - t2, t1 + t2, t2 - t1, t1 - t3 of the row's 4 columns t.
+    // With 8 waves a thread does half of that: columns c0 .. c0 + 2 (c0 = 0: j = 0, 1;  c0 = 1: j = 3, 2), as
+    //   d = first - third -> j = 0 | 3,     e = second + sg2 * (third | first) -> j = 1 | 2.
+    constexpr int TC = (CHB == 2) ? 4 : 3;          // raw columns a thread reads
+    const int t_hs = (CHB == 2) ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int t_cq = tid & 1, t_tx = (tid >> 1) & 15, t_i = (tid >> 5) & 3, t_ty = (tid >> 7) & 1;
+    const int t_src = ((2 * t_ty) * kRawW + 2 * t_tx + t_hs) * kRS + t_cq * 4;
     const int rowA = (t_i == 0) ? 0 : (t_i == 2 ? 2 : 1);
     const int rowB = (t_i == 0 || t_i == 1) ? 2 : (t_i == 2 ? 1 : 3);
     const int t_offA = t_src + rowA * kRawW * kRS, t_offB = t_src + rowB * kRawW * kRS;
     const float t_sgn = (t_i == 1) ? 1.0f : -1.0f;
     const int t_dst = t_i * 4 * kUC + (t_ty * 16 + t_tx) * kUS + t_cq * 4;
-    auto transform = [&](int rbase, int ubase) {
-        float4 tt[4];
+    const float t_sg2 = t_hs ? -1.0f : 1.0f;
+    const int t_jd = t_hs ? 3 * kUC : 0, t_je = t_hs ? 2 * kUC : kUC;
+    auto sub4 = [](float4 p, float4 q) { return make_float4(p.x - q.x, p.y - q.y, p.z - q.z, p.w - q.w); };
+    auto add4 = [](float4 p, float4 q) { return make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w); };
+    auto fma4 = [](float sg, float4 q, float4 p) { return make_float4(fmaf(sg, q.x, p.x), fmaf(sg, q.y, p.y), fmaf(sg, q.z, p.z), fmaf(sg, q.w, p.w)); };
+    float4 tp[TC], tq[TC], tt[TC];
+    auto tr_read = [&](int rbase) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 p = *reinterpret_cast<const float4*>(&lds[rbase + t_offA + c * kRS]);
-            const float4 q = *reinterpret_cast<const float4*>(&lds[rbase + t_offB + c * kRS]);
-            tt[c] = make_float4(fmaf(t_sgn, q.x, p.x), fmaf(t_sgn, q.y, p.y), fmaf(t_sgn, q.z, p.z), fmaf(t_sgn, q.w, p.w));
+        for (int c = 0; c < TC; ++c) {
+            tp[c] = *reinterpret_cast<const float4*>(&lds[rbase + t_offA + c * kRS]);
+            tq[c] = *reinterpret_cast<const float4*>(&lds[rbase + t_offB + c * kRS]);
         }
+    };
+    auto tr_row = [&](int c) { if (c < TC) tt[c] = fma4(t_sgn, tq[c], tp[c]); };
+    auto tr_out = [&](int ubase, int half) {        // half 0 / 1: the first / second half of the thread's U stores
         float* u = &lds[ubase + t_dst];
-        *reinterpret_cast<float4*>(u) = make_float4(tt[0].x - tt[2].x, tt[0].y - tt[2].y, tt[0].z - tt[2].z, tt[0].w - tt[2].w);
-        *reinterpret_cast<float4*>(u + kUC) = make_float4(tt[1].x + tt[2].x, tt[1].y + tt[2].y, tt[1].z + tt[2].z, tt[1].w + tt[2].w);
-        *reinterpret_cast<float4*>(u + 2 * kUC) = make_float4(tt[2].x - tt[1].x, tt[2].y - tt[1].y, tt[2].z - tt[1].z, tt[2].w - tt[1].w);
-        *reinterpret_cast<float4*>(u + 3 * kUC) = make_float4(tt[1].x - tt[3].x, tt[1].y - tt[3].y, tt[1].z - tt[3].z, tt[1].w - tt[3].w);
+        if (CHB == 2) {
+            if (half == 0) {
+                *reinterpret_cast<float4*>(u) = sub4(tt[0], tt[2]);
+                *reinterpret_cast<float4*>(u + kUC) = add4(tt[1], tt[2]);
+            } else {
+                *reinterpret_cast<float4*>(u + 2 * kUC) = sub4(tt[2], tt[1]);
+                *reinterpret_cast<float4*>(u + 3 * kUC) = sub4(tt[1], tt[TC - 1]);
+            }
+        } else {
+            if (half == 0) {
+                *reinterpret_cast<float4*>(u + t_jd) = sub4(tt[0], tt[2]);
+            } else {
+                const float4 sel = t_hs ? tt[0] : tt[2];
+                *reinterpret_cast<float4*>(u + t_je) = fma4(t_sg2, sel, tt[1]);
+            }
+        }
+    };
+    auto transform = [&](int rbase, int ubase) {
+        tr_read(rbase);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tr_row(c);
+        tr_out(ubase, 0);
+        tr_out(ubase, 1);
     };
 
     float4 bw[8], af[2][4];              // filter fragments of a chunk; A fragments of the two groups of 4 components
@@ -190,13 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a)
         const int rnxt = 2 * kUFloats + ((kc + 1) & 1) * kRFloats, rfill = 2 * kUFloats + (kc & 1) * kRFloats;
         const float4* wnext = wlane + (int64_t)min(kc + 1, nK - 1) * (16 * 2 * 64);
         af_read(ucur, 1);
-        float4 tp[4], tq[4], tt[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            tp[c] = *reinterpret_cast<const float4*>(&lds[rnxt + t_offA + c * kRS]);
-            tq[c] = *reinterpret_cast<const float4*>(&lds[rnxt + t_offB + c * kRS]);
-        }
-        float* u = &lds[unxt + t_dst];
+        tr_read(rnxt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -212,18 +242,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a)
                 }
                 if (g == 0) {
                     if (t < 2) {
-#pragma unroll
-                        for (int c = 2 * t; c < 2 * t + 2; ++c)
-                            tt[c] = make_float4(fmaf(t_sgn, tq[c].x, tp[c].x), fmaf(t_sgn, tq[c].y, tp[c].y), fmaf(t_sgn, tq[c].z, tp[c].z),
-                                                fmaf(t_sgn, tq[c].w, tp[c].w));
+                        tr_row(2 * t);
+                        tr_row(2 * t + 1);
                     }
-                    if (t == 2) {
-                        *reinterpret_cast<float4*>(u) = make_float4(tt[0].x - tt[2].x, tt[0].y - tt[2].y, tt[0].z - tt[2].z, tt[0].w - tt[2].w);
-                        *reinterpret_cast<float4*>(u + kUC) = make_float4(tt[1].x + tt[2].x, tt[1].y + tt[2].y, tt[1].z + tt[2].z, tt[1].w + tt[2].w);
-                    }
+                    if (t == 2) tr_out(unxt, 0);
                     if (t == 3) {
-                        *reinterpret_cast<float4*>(u + 2 * kUC) = make_float4(tt[2].x - tt[1].x, tt[2].y - tt[1].y, tt[2].z - tt[1].z, tt[2].w - tt[1].w);
-                        *reinterpret_cast<float4*>(u + 3 * kUC) = make_float4(tt[1].x - tt[3].x, tt[1].y - tt[3].y, tt[1].z - tt[3].z, tt[1].w - tt[3].w);
+                        tr_out(unxt, 1);
                         store_raw(rfill);
                     }
                 }
@@ -269,8 +293,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a)
     // output pass: thread -> (pixel, 4 channels); sum of the two staging areas, max-pool, bias, residual, ReLU
     constexpr int kOutW = (POOL == 1) ? 16 : 32;               // output pixels per tile row
     constexpr int kOutPx = (POOL == 0) ? 128 : (POOL == 1 ? 32 : 64);
-    const int c4 = tid & 15;
-    const int co0 = nb * 64 + c4 * 4;
+    const int c4 = tid % (NCH / 4);
+    const int co0 = nb * NCH + c4 * 4;
     const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + co0);          // bias is padded to cout_pad
     const int Ho = (POOL == 0) ? a.H : a.H / 2, Wo = (POOL == 1) ? a.W / 2 : a.W;
     const int oy0 = (POOL == 0) ? y0 : (y0 >> 1), ox0 = (POOL == 1) ? (x0 >> 1) : x0;
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoArgs a)
     };
     auto max4 = [](float4 p, float4 q) { return make_float4(fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), fmaxf(p.w, q.w)); };
 #pragma unroll 2
-    for (int px = tid >> 4; px < kOutPx; px += 16) {
+    for (int px = tid / (NCH / 4); px < kOutPx; px += 16) {
         const int py = px / kOutW, pxx = px % kOutW;
         const int yy = oy0 + py;
         int xx = ox0 + pxx, ob = b;
@@ -379,32 +403,40 @@ int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H,
         }
     }
     a.tiles_per_image = a.tiles_x * ((H + 3) / 4);
-    a.n_blocks_n = L.cout_pad / 64;
+    // 128 channels per workgroup (8 waves, one workgroup per CU) for the deep layers: the transform and the raw tile are
+    // then shared by twice as many MFMAs (measured +5 % at 256 and 512 input channels); 64 channels (4 waves, two
+    // workgroups per CU) where K is short (the per-workgroup start-up and epilogue weigh more than the transform: equal
+    // or slower at 64 input channels) or where 128-channel workgroups would not fill the CUs
+    const int64_t wgs128 = (int64_t)a.tiles_per_image * (L.cout_pad / 128) * a.B;
+    const int chb = (L.cout_pad % 128 == 0 && L.cin >= 128 && wgs128 >= 256) ? 4 : 2;
+    a.n_blocks_n = L.cout_pad / (32 * chb);
     const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * a.B;
     OCR_REQUIRE(wgs < (1ll << 31), "conv_wino: too many workgroups");
     char pname[64];
-    std::snprintf(pname, sizeof(pname), "conv_wino_f32<n64,pool%d,tile4x32>", pool);
+    std::snprintf(pname, sizeof(pname), "conv_wino_f32<n%d,pool%d,tile4x32>", 32 * chb, pool);
     const double out_px = (double)B * H * W;
     const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : (pool == 2 ? 2.0 : 1.0));
     ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
                    4.0 * (out_px * L.cin + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout), s);
-    const dim3 grid((unsigned)wgs), block(256);
+    const dim3 grid((unsigned)wgs), block(128 * chb);
     static bool lds_opt_in_dev[64] = {};        // more than 64 KB of LDS per workgroup needs an opt-in per kernel and device
     int dev = 0;
     OCR_HIP_CHECK(hipGetDevice(&dev));
     bool& lds_opt_in = lds_opt_in_dev[dev & 63];
+#define OCR_WINO_FOR_ALL(X) X(0, 2) X(1, 2) X(2, 2) X(0, 4) X(1, 4) X(2, 4)
     if (!lds_opt_in) {
-        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+#define OCR_WINO_OPT_IN(P, C)                                                                                              \
+    OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel<P, C>),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(C)));
+        OCR_WINO_FOR_ALL(OCR_WINO_OPT_IN)
+#undef OCR_WINO_OPT_IN
         lds_opt_in = true;
     }
-    if (pool == 0)
-        hipLaunchKernelGGL(conv_wino_f32_kernel<0>, grid, block, kLdsBytes, s, a);
-    else if (pool == 1)
-        hipLaunchKernelGGL(conv_wino_f32_kernel<1>, grid, block, kLdsBytes, s, a);
-    else
-        hipLaunchKernelGGL(conv_wino_f32_kernel<2>, grid, block, kLdsBytes, s, a);
+#define OCR_WINO_LAUNCH(P, C)                                                                                              \
+    if (pool == P && chb == C) hipLaunchKernelGGL((conv_wino_f32_kernel<P, C>), grid, block, lds_bytes(C), s, a);
+    OCR_WINO_FOR_ALL(OCR_WINO_LAUNCH)
+#undef OCR_WINO_LAUNCH
+#undef OCR_WINO_FOR_ALL
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }
