@@ -305,8 +305,20 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
         return make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
     };
     auto max4 = [](float4 p, float4 q) { return make_float4(fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), fmaxf(p.w, q.w)); };
-#pragma unroll 2
-    for (int px = tid / (NCH / 4); px < kOutPx; px += 16) {
+    // all staged values first (one LDS round trip for the whole pass), then the stores
+    constexpr int kIters = kOutPx / 16;
+    float4 vals[kIters];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const int px = tid / (NCH / 4) + it * 16;
+        const int py = px / kOutW, pxx = px % kOutW;
+        if (POOL == 0) vals[it] = staged(py, pxx);
+        else if (POOL == 1) vals[it] = max4(max4(staged(2 * py, 2 * pxx), staged(2 * py, 2 * pxx + 1)), max4(staged(2 * py + 1, 2 * pxx), staged(2 * py + 1, 2 * pxx + 1)));
+        else vals[it] = max4(staged(2 * py, pxx), staged(2 * py + 1, pxx));
+    }
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const int px = tid / (NCH / 4) + it * 16;
         const int py = px / kOutW, pxx = px % kOutW;
         const int yy = oy0 + py;
         int xx = ox0 + pxx, ob = b;
@@ -317,10 +329,7 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
             if (ob >= a.vB) continue;
         }
         if (yy >= Ho || xx >= Wo) continue;
-        float4 val;
-        if (POOL == 0) val = staged(py, pxx);
-        else if (POOL == 1) val = max4(max4(staged(2 * py, 2 * pxx), staged(2 * py, 2 * pxx + 1)), max4(staged(2 * py + 1, 2 * pxx), staged(2 * py + 1, 2 * pxx + 1)));
-        else val = max4(staged(2 * py, pxx), staged(2 * py + 1, pxx));
+        float4 val = vals[it];
         val.x += bias4.x; val.y += bias4.y; val.z += bias4.z; val.w += bias4.w;
         const int64_t idx = (((int64_t)ob * Ho + yy) * Wo + xx) * a.cout + co0;
         if (vec_ok) {
