@@ -28,6 +28,8 @@
 //
 // Roofline: MFMA bound; the unit of work is the direct convolution's 2*9*Cin*Cout flop per output pixel, of
 // which 16/36 are executed.
+#include <type_traits>
+
 #include "common.h"
 
 namespace ocrhip {
@@ -35,6 +37,8 @@ namespace ocrhip {
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));     // arithmetic on these compiles to packed f32 instructions
 
 constexpr int kCK = 8;            // input channels per chunk
 constexpr int kRS = 12;           // floats per raw pixel in LDS (8 + pad: conflict-free 16-byte reads)
@@ -44,7 +48,8 @@ constexpr int kBlocks = 32;       // 2 block rows x 16 block columns
 constexpr int kUC = kBlocks * kUS;            // floats per component of U
 constexpr int kUFloats = 16 * kUC;            // one U buffer: 24 KB
 constexpr int kRFloats = kRawPx * kRS;        // one raw-tile buffer: 9.6 KB
-constexpr int kLoopFloats = 2 * kUFloats + 2 * kRFloats + 4;
+constexpr int kRBuf = kRFloats + 4;            // + a spare slot for the threads without a pixel
+constexpr int kLoopFloats = 2 * kUFloats + 2 * kRBuf;
 // CHB = channel blocks of 32 per workgroup (2 or 4); the epilogue stages 2 x 128 pixels x (32 CHB + 4) floats
 constexpr int lds_bytes(int chb) {
     return 4 * (kLoopFloats > 2 * 128 * (32 * chb + 4) ? kLoopFloats : 2 * 128 * (32 * chb + 4));
@@ -95,45 +100,50 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[f][v] = 0.0f;
 
+    // Global loads go through buffer descriptors: a per-lane 32-bit byte offset that never changes, the chunk as a
+    // scalar offset, and the hardware's range check, which returns zeros for an offset beyond the buffer - the zero
+    // padding around the image costs no instruction (lanes outside the image carry the offset 2^31).
     // weight slab of a block of 64 channels: [k chunk][component][channel half][lane][4]
-    const float4* wlane = reinterpret_cast<const float4*>(a.w) + (int64_t)(nb * (CHB / 2) + (ch >> 1)) * nK * (16 * 2 * 64) +
-                          (fh * 8) * 128 + (ch & 1) * 64 + lane;
+    const float* wslab = a.w + (int64_t)(nb * (CHB / 2) + (ch >> 1)) * nK * (16 * 2 * 64 * 4);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wslab, 0, nK * (16 * 2 * 64 * 16), 0x00020000);
+    const int w_off0 = ((fh * 8) * 128 + (ch & 1) * 64 + lane) * 16, w_off1 = w_off0 + 2048;
+    auto load_w = [&](int kc, int f) {          // fragment of component 8 fh + f of chunk kc
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (f & 1) ? w_off1 : w_off0,
+                                                                                kc * (16 * 2 * 64 * 16) + (f >> 1) * 4096, 0));
+    };
 
-    // raw tile: 204 pixels x 2 channel quads over the threads (two or one per thread); addresses are fixed per thread.
-    // Loads and stores are unconditional (pixels outside the image read the first pixel of the image and are replaced
-    // by zeros on the way to LDS; threads without a pixel store to a spare slot).
+    // raw tile: 204 pixels x 2 channel quads over the threads (two or one per thread); offsets are fixed per thread;
+    // threads without a pixel store to a spare slot
     constexpr int NRAW = (kRawPx * 2 + NT - 1) / NT;
+    const int64_t img_floats = (int64_t)a.H * a.W * a.cin;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + (a.vP > 0 ? 0 : b * img_floats)), 0, (int)((a.vP > 0 ? a.vB : 1) * img_floats * 4), 0x00020000);
     float4 ra[NRAW];
-    int64_t raw_src[NRAW];
-    int raw_dst[NRAW];
-    bool raw_ok[NRAW];
-    constexpr int kDummy = 2 * kUFloats + 2 * kRFloats;     // 16 spare bytes behind the buffers
+    int raw_src[NRAW], raw_dst[NRAW];
 #pragma unroll
     for (int i = 0; i < NRAW; ++i) {
         const int f = tid + i * NT;
         const int px = f >> 1, c4 = f & 1;
         const int gy = y0 - 1 + px / kRawW;
-        int gx = x0 - 1 + px % kRawW, gb = b;
+        int gx = x0 - 1 + px % kRawW, gb = 0;
         bool in_x = gx >= 0;
         if (a.vP > 0 && in_x) {
             gb = gx / a.vP;
             gx -= gb * a.vP;
             in_x = gb < a.vB;
         }
-        raw_ok[i] = f < kRawPx * 2 && gy >= 0 && gy < a.H && in_x && gx < a.W;
-        raw_src[i] = raw_ok[i] ? ((((int64_t)gb * a.H + gy) * a.W + gx) * a.cin + c4 * 4) : (int64_t)b * a.H * a.W * a.cin;
-        raw_dst[i] = (f < kRawPx * 2) ? (px * kRS + c4 * 4) : kDummy;
+        const bool ok = f < kRawPx * 2 && gy >= 0 && gy < a.H && in_x && gx < a.W;
+        raw_src[i] = ok ? ((((gb * a.H + gy) * a.W + gx) * a.cin + c4 * 4) * 4) : (int)0x80000000;
+        raw_dst[i] = (f < kRawPx * 2) ? (px * kRS + c4 * 4) : kRFloats;
     }
     auto load_raw = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < NRAW; ++i) ra[i] = *reinterpret_cast<const float4*>(a.x + raw_src[i] + kc * kCK);
+        for (int i = 0; i < NRAW; ++i)
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, raw_src[i], kc * (kCK * 4), 0));
     };
     auto store_raw = [&](int rbase) {
 #pragma unroll
-        for (int i = 0; i < NRAW; ++i) {
-            const int idx = raw_dst[i] == kDummy ? kDummy : rbase + raw_dst[i];
-            *reinterpret_cast<float4*>(&lds[idx]) = raw_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < NRAW; ++i) *reinterpret_cast<float4*>(&lds[rbase + raw_dst[i]]) = ra[i];
     };
 
     // Data transform: a thread owns (block, 4 channels, component row i):
@@ -152,34 +162,31 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
     const int t_dst = t_i * 4 * kUC + (t_ty * 16 + t_tx) * kUS + t_cq * 4;
     const float t_sg2 = t_hs ? -1.0f : 1.0f;
     const int t_jd = t_hs ? 3 * kUC : 0, t_je = t_hs ? 2 * kUC : kUC;
-    auto sub4 = [](float4 p, float4 q) { return make_float4(p.x - q.x, p.y - q.y, p.z - q.z, p.w - q.w); };
-    auto add4 = [](float4 p, float4 q) { return make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w); };
-    auto fma4 = [](float sg, float4 q, float4 p) { return make_float4(fmaf(sg, q.x, p.x), fmaf(sg, q.y, p.y), fmaf(sg, q.z, p.z), fmaf(sg, q.w, p.w)); };
-    float4 tp[TC], tq[TC], tt[TC];
+    floatx4 tp[TC], tq[TC], tt[TC];
     auto tr_read = [&](int rbase) {
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
-            tp[c] = *reinterpret_cast<const float4*>(&lds[rbase + t_offA + c * kRS]);
-            tq[c] = *reinterpret_cast<const float4*>(&lds[rbase + t_offB + c * kRS]);
+            tp[c] = *reinterpret_cast<const floatx4*>(&lds[rbase + t_offA + c * kRS]);
+            tq[c] = *reinterpret_cast<const floatx4*>(&lds[rbase + t_offB + c * kRS]);
         }
     };
-    auto tr_row = [&](int c) { if (c < TC) tt[c] = fma4(t_sgn, tq[c], tp[c]); };
+    auto tr_row = [&](int c) { if (c < TC) tt[c] = tq[c] * t_sgn + tp[c]; };
     auto tr_out = [&](int ubase, int half) {        // half 0 / 1: the first / second half of the thread's U stores
         float* u = &lds[ubase + t_dst];
         if (CHB == 2) {
             if (half == 0) {
-                *reinterpret_cast<float4*>(u) = sub4(tt[0], tt[2]);
-                *reinterpret_cast<float4*>(u + kUC) = add4(tt[1], tt[2]);
+                *reinterpret_cast<floatx4*>(u) = tt[0] - tt[2];
+                *reinterpret_cast<floatx4*>(u + kUC) = tt[1] + tt[2];
             } else {
-                *reinterpret_cast<float4*>(u + 2 * kUC) = sub4(tt[2], tt[1]);
-                *reinterpret_cast<float4*>(u + 3 * kUC) = sub4(tt[1], tt[TC - 1]);
+                *reinterpret_cast<floatx4*>(u + 2 * kUC) = tt[2] - tt[1];
+                *reinterpret_cast<floatx4*>(u + 3 * kUC) = tt[1] - tt[TC - 1];
             }
         } else {
             if (half == 0) {
-                *reinterpret_cast<float4*>(u + t_jd) = sub4(tt[0], tt[2]);
+                *reinterpret_cast<floatx4*>(u + t_jd) = tt[0] - tt[2];
             } else {
-                const float4 sel = t_hs ? tt[0] : tt[2];
-                *reinterpret_cast<float4*>(u + t_je) = fma4(t_sg2, sel, tt[1]);
+                const floatx4 sel = t_hs ? tt[0] : tt[2];
+                *reinterpret_cast<floatx4*>(u + t_je) = sel * t_sg2 + tt[1];
             }
         }
     };
@@ -200,10 +207,10 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
 
     // prologue: chunk 0 transformed into U[0], raw tile 1 in raw[1], raw tile 2 on its way to registers, filter
     // fragments of chunk 0 and the A fragments of its first group in registers
-    constexpr int kR0 = 2 * kUFloats, kR1 = 2 * kUFloats + kRFloats;
+    constexpr int kR0 = 2 * kUFloats, kR1 = 2 * kUFloats + kRBuf;
     load_raw(0);
 #pragma unroll
-    for (int f = 0; f < 8; ++f) bw[f] = wlane[f * 128];
+    for (int f = 0; f < 8; ++f) bw[f] = load_w(0, f);
     store_raw(kR0);
     load_raw(min(1, nK - 1));
     __syncthreads();
@@ -218,13 +225,17 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
     // filter fragments of the chunk in registers, raw tile kc + 1 in raw[(kc + 1) & 1], raw tile kc + 2 in flight.
     //   group 0: A fragments of group 1 requested; transform of chunk kc + 1 (raw[(kc + 1) & 1] -> U[(kc + 1) & 1]) between
     //            the MFMAs; raw tile kc + 2 into raw[kc & 1]; filter fragments 0..3 reloaded for chunk kc + 1
-    //   barrier: U[(kc + 1) & 1] and raw tile kc + 2 visible; nobody reads U[kc & 1]... group 1 still does, from registers
+    //   barrier: U[(kc + 1) & 1] and raw tile kc + 2 visible; group 1 works from registers
     //   group 1: A fragments of group 0 of chunk kc + 1 and raw tile kc + 3 requested; filter fragments 4..7 reloaded
     // Past the end of K the same loads and stores run on the last chunk again and their results are not used.
-    for (int kc = 0; kc < nK; ++kc) {
-        const int ucur = (kc & 1) * kUFloats, unxt = ((kc + 1) & 1) * kUFloats;
-        const int rnxt = 2 * kUFloats + ((kc + 1) & 1) * kRFloats, rfill = 2 * kUFloats + (kc & 1) * kRFloats;
-        const float4* wnext = wlane + (int64_t)min(kc + 1, nK - 1) * (16 * 2 * 64);
+    // The loop is unrolled over the buffer parity, so every LDS address is a register that never changes plus an
+    // immediate: between the MFMAs the vector ALU only does the transform's arithmetic (on this hardware every other
+    // vector instruction delays the next MFMA by its own duration, even when a second wave has MFMAs ready).
+    auto chunk = [&](int kc, auto parity) {
+        constexpr int P = decltype(parity)::value;
+        constexpr int ucur = P * kUFloats, unxt = (1 - P) * kUFloats;
+        constexpr int rnxt = kR0 + (1 - P) * kRBuf, rfill = kR0 + P * kRBuf;
+        const int kn = min(kc + 1, nK - 1);
         af_read(ucur, 1);
         tr_read(rnxt);
         __builtin_amdgcn_sched_barrier(0);
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bw[g * 4 + i] = wnext[(g * 4 + i) * 128];
+            for (int i = 0; i < 4; ++i) bw[g * 4 + i] = load_w(kn, g * 4 + i);
             if (g == 0) {
                 __syncthreads();
                 af_read(unxt, 0);
@@ -262,6 +273,10 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    };
+    for (int kc = 0; kc < nK; kc += 2) {        // nK is even
+        chunk(kc, std::integral_constant<int, 0>{});
+        chunk(kc + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- inverse transform.  Register v of a lane belongs to block m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5) of the
@@ -271,22 +286,26 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
     __syncthreads();                                           // every wave is done with U
     float* O = lds + fh * kStage;
     const int oc = ch * 32 + li;
+    floatx16 r0[2], r1[2];                 // this wave's share of output rows 0 and 1, columns c = 0, 1 of every block
+    {
+        const floatx16 z00 = acc[0] + acc[1] + acc[2], z01 = acc[1] - acc[2] - acc[3];
+        const floatx16 z10 = acc[4] + acc[5] + acc[6], z11 = acc[5] - acc[6] - acc[7];
+        if (fh == 0) {
+            r0[0] = z00 + z10; r0[1] = z01 + z11;
+            r1[0] = z10;       r1[1] = z11;
+        } else {
+            r0[0] = z00;        r0[1] = z01;
+            r1[0] = -z00 - z10; r1[1] = -z01 - z11;
+        }
+    }
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int m = (v & 3) + 8 * (v >> 2) + 4 * lh;
         const int ty = m >> 4, tx = m & 15;
-        float z[2][2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            z[r][0] = acc[4 * r][v] + acc[4 * r + 1][v] + acc[4 * r + 2][v];
-            z[r][1] = acc[4 * r + 1][v] - acc[4 * r + 2][v] - acc[4 * r + 3][v];
-        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float r0 = fh == 0 ? z[0][c] + z[1][c] : z[0][c];
-            const float r1 = fh == 0 ? z[1][c] : -z[0][c] - z[1][c];
-            O[((2 * ty) * 32 + 2 * tx + c) * kOS + oc] = r0;
-            O[((2 * ty + 1) * 32 + 2 * tx + c) * kOS + oc] = r1;
+            O[((2 * ty) * 32 + 2 * tx + c) * kOS + oc] = r0[c][v];
+            O[((2 * ty + 1) * 32 + 2 * tx + c) * kOS + oc] = r1[c][v];
         }
     }
     __syncthreads();
@@ -295,19 +314,18 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
     constexpr int kOutPx = (POOL == 0) ? 128 : (POOL == 1 ? 32 : 64);
     const int c4 = tid % (NCH / 4);
     const int co0 = nb * NCH + c4 * 4;
-    const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + co0);          // bias is padded to cout_pad
+    const floatx4 bias4 = *reinterpret_cast<const floatx4*>(a.bias + co0);          // bias is padded to cout_pad
     const int Ho = (POOL == 0) ? a.H : a.H / 2, Wo = (POOL == 1) ? a.W / 2 : a.W;
     const int oy0 = (POOL == 0) ? y0 : (y0 >> 1), ox0 = (POOL == 1) ? (x0 >> 1) : x0;
     const bool vec_ok = (a.cout & 3) == 0 && co0 + 3 < a.cout;
     auto staged = [&](int row, int col) {
-        const float4 p = *reinterpret_cast<const float4*>(&lds[(row * 32 + col) * kOS + c4 * 4]);
-        const float4 q = *reinterpret_cast<const float4*>(&lds[kStage + (row * 32 + col) * kOS + c4 * 4]);
-        return make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+        return *reinterpret_cast<const floatx4*>(&lds[(row * 32 + col) * kOS + c4 * 4]) +
+               *reinterpret_cast<const floatx4*>(&lds[kStage + (row * 32 + col) * kOS + c4 * 4]);
     };
-    auto max4 = [](float4 p, float4 q) { return make_float4(fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), fmaxf(p.w, q.w)); };
+    auto max4 = [](floatx4 p, floatx4 q) { return floatx4{fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), fmaxf(p.w, q.w)}; };
     // all staged values first (one LDS round trip for the whole pass), then the stores
     constexpr int kIters = kOutPx / 16;
-    float4 vals[kIters];
+    floatx4 vals[kIters];
 #pragma unroll
     for (int it = 0; it < kIters; ++it) {
         const int px = tid / (NCH / 4) + it * 16;
@@ -329,18 +347,16 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
             if (ob >= a.vB) continue;
         }
         if (yy >= Ho || xx >= Wo) continue;
-        float4 val = vals[it];
-        val.x += bias4.x; val.y += bias4.y; val.z += bias4.z; val.w += bias4.w;
+        floatx4 val = vals[it] + bias4;
         const int64_t idx = (((int64_t)ob * Ho + yy) * Wo + xx) * a.cout + co0;
         if (vec_ok) {
             if (POOL == 0 && a.res) {
-                const float4 rr = *reinterpret_cast<const float4*>(a.res + idx);
-                val.x += rr.x; val.y += rr.y; val.z += rr.z; val.w += rr.w;
+                val += *reinterpret_cast<const floatx4*>(a.res + idx);
             }
             if (a.relu) {
                 val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
             }
-            *reinterpret_cast<float4*>(a.y + idx) = val;
+            *reinterpret_cast<floatx4*>(a.y + idx) = val;
         } else {
             const float e[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
@@ -362,7 +378,7 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
 // float32 with output channel = nblock * 64 + c * 32 + j32 and input channel = kchunk * 8 + 4h + t, i.e. lane
 // (h * 32 + j32) of the wave that owns channel half c reads 16 consecutive bytes.
 int prepare_conv_wino(ConvLayer& L, const float* w_oihw, int cout, int cin) {
-    OCR_REQUIRE(cin % kCK == 0 && cout > 0, "conv_wino: cin=%d must be a multiple of %d", cin, kCK);
+    OCR_REQUIRE(cin % (2 * kCK) == 0 && cout > 0, "conv_wino: cin=%d must be a multiple of %d", cin, 2 * kCK);
     const int nN = (cout + 63) / 64, nK = cin / kCK;
     std::vector<float> w((size_t)nN * nK * 16 * 2 * 64 * 4, 0.0f);
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
@@ -390,7 +406,8 @@ int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H,
                       const float* residual, hipStream_t s) {
     OCR_REQUIRE(L.ks == 3 && L.w_wino.ptr, "conv_wino: layer has no transformed filters");
     OCR_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "conv_wino: bad arguments B=%d H=%d W=%d", B, H, W);
-    OCR_REQUIRE(L.cout_pad % 64 == 0 && L.cin % kCK == 0, "conv_wino: layer shape %d -> %d not supported", L.cin, L.cout);
+    OCR_REQUIRE(L.cout_pad % 64 == 0 && L.cin % (2 * kCK) == 0, "conv_wino: layer shape %d -> %d not supported", L.cin, L.cout);
+    OCR_REQUIRE((int64_t)H * W * L.cin * 4 < (1ll << 31), "conv_wino: image of %dx%dx%d floats exceeds the 2 GB of a buffer descriptor", H, W, L.cin);
     OCR_REQUIRE(pool >= 0 && pool <= 2, "conv_wino: bad pool mode %d", pool);
     if (pool) OCR_REQUIRE(H % 2 == 0 && (pool == 2 || W % 2 == 0), "conv_wino: pooled layer needs even size, got %dx%d", H, W);
     OCR_REQUIRE(!residual || pool == 0, "conv_wino: a residual goes with an unpooled layer");
@@ -405,7 +422,7 @@ int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H,
     if (B > 1 && W % 32 != 0) {
         const int period = W + (pool == 1 ? 2 : 1);
         const int64_t vw = (int64_t)B * period;
-        if (vw < (1ll << 30) && (vw + 31) / 32 < (int64_t)a.tiles_x * B) {
+        if (vw < (1ll << 30) && (int64_t)B * H * W * L.cin * 4 < (1ll << 31) && (vw + 31) / 32 < (int64_t)a.tiles_x * B) {
             a.vP = period;
             a.B = 1;
             a.tiles_x = (int)((vw + 31) / 32);
