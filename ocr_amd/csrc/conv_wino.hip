@@ -38,7 +38,27 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));     // arithmetic on these compiles to packed f32 instructions
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// Packed f32 arithmetic as inline assembly: one instruction for two floats at the price of one.  Written as vector
+// expressions the compiler selects the same instructions but splits them into scalar ones again wherever MFMAs are
+// near, which doubles the vector-ALU time between the MFMAs.
+__device__ __forceinline__ floatx2 pk_fma(floatx2 a, floatx2 b, floatx2 c) {
+    floatx2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ floatx2 pk_add(floatx2 a, floatx2 b) {
+    floatx2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
+    floatx2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}     // arithmetic on these compiles to packed f32 instructions
 
 constexpr int kCK = 8;            // input channels per chunk
 constexpr int kRS = 12;           // floats per raw pixel in LDS (8 + pad: conflict-free 16-byte reads)
@@ -150,7 +170,7 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
     //   i = 0: d0 - d2,  i = 1: d1 + d2,  i = 2: d2 - d1,  i = 3: d1 - d3     (rows of B^T d) = dA + sgn * dB,
     // then (.) B along the columns: components j = 0..3 = t0 - t2, t1 + t2, t2 - t1, t1 - t3 of the row's 4 columns t.
     // With 8 waves a thread does half of that: columns c0 .. c0 + 2 (c0 = 0: j = 0, 1;  c0 = 1: j = 3, 2), as
-    //   d = first - third -> j = 0 | 3,     e = second + sg2 * (third | first) -> j = 1 | 2.
+    //   d = first - third -> j = 0 | 3,     e = second + third | second - first -> j = 1 | 2.
     constexpr int TC = (CHB == 2) ? 4 : 3;          // raw columns a thread reads
     const int t_hs = (CHB == 2) ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);
     const int t_cq = tid & 1, t_tx = (tid >> 1) & 15, t_i = (tid >> 5) & 3, t_ty = (tid >> 7) & 1;
@@ -158,11 +178,14 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
     const int rowA = (t_i == 0) ? 0 : (t_i == 2 ? 2 : 1);
     const int rowB = (t_i == 0 || t_i == 1) ? 2 : (t_i == 2 ? 1 : 3);
     const int t_offA = t_src + rowA * kRawW * kRS, t_offB = t_src + rowB * kRawW * kRS;
-    const float t_sgn = (t_i == 1) ? 1.0f : -1.0f;
+    const float t_sgn1 = (t_i == 1) ? 1.0f : -1.0f;
+    const floatx2 t_sgn = {t_sgn1, t_sgn1};
     const int t_dst = t_i * 4 * kUC + (t_ty * 16 + t_tx) * kUS + t_cq * 4;
-    const float t_sg2 = t_hs ? -1.0f : 1.0f;
+    // 8 waves: e = second + s0 * first + s2 * third with (s0, s2) = (0, 1) for j = 1 and (-1, 0) for j = 2
+    const floatx2 t_s0 = {t_hs ? -1.0f : 0.0f, t_hs ? -1.0f : 0.0f}, t_s2 = {t_hs ? 0.0f : 1.0f, t_hs ? 0.0f : 1.0f};
     const int t_jd = t_hs ? 3 * kUC : 0, t_je = t_hs ? 2 * kUC : kUC;
-    floatx4 tp[TC], tq[TC], tt[TC];
+    floatx4 tp[TC], tq[TC];
+    floatx2 tt[TC][2];                     // B^T d row of this thread: column, channel pair
     auto tr_read = [&](int rbase) {
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
@@ -170,23 +193,32 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
             tq[c] = *reinterpret_cast<const floatx4*>(&lds[rbase + t_offB + c * kRS]);
         }
     };
-    auto tr_row = [&](int c) { if (c < TC) tt[c] = tq[c] * t_sgn + tp[c]; };
+    auto tr_row = [&](int c) {
+        if (c < TC) {
+            tt[c][0] = pk_fma(t_sgn, tq[c].xy, tp[c].xy);
+            tt[c][1] = pk_fma(t_sgn, tq[c].zw, tp[c].zw);
+        }
+    };
+    auto put2 = [&](float* u, floatx2 lo, floatx2 hi) {       // two 8-byte stores: no need for 4 consecutive registers
+        *reinterpret_cast<floatx2*>(u) = lo;
+        *reinterpret_cast<floatx2*>(u + 2) = hi;
+    };
     auto tr_out = [&](int ubase, int half) {        // half 0 / 1: the first / second half of the thread's U stores
         float* u = &lds[ubase + t_dst];
         if (CHB == 2) {
             if (half == 0) {
-                *reinterpret_cast<floatx4*>(u) = tt[0] - tt[2];
-                *reinterpret_cast<floatx4*>(u + kUC) = tt[1] + tt[2];
+                put2(u, pk_sub(tt[0][0], tt[2][0]), pk_sub(tt[0][1], tt[2][1]));
+                put2(u + kUC, pk_add(tt[1][0], tt[2][0]), pk_add(tt[1][1], tt[2][1]));
             } else {
-                *reinterpret_cast<floatx4*>(u + 2 * kUC) = tt[2] - tt[1];
-                *reinterpret_cast<floatx4*>(u + 3 * kUC) = tt[1] - tt[TC - 1];
+                put2(u + 2 * kUC, pk_sub(tt[2][0], tt[1][0]), pk_sub(tt[2][1], tt[1][1]));
+                put2(u + 3 * kUC, pk_sub(tt[1][0], tt[TC - 1][0]), pk_sub(tt[1][1], tt[TC - 1][1]));
             }
         } else {
             if (half == 0) {
-                *reinterpret_cast<floatx4*>(u + t_jd) = tt[0] - tt[2];
+                put2(u + t_jd, pk_sub(tt[0][0], tt[2][0]), pk_sub(tt[0][1], tt[2][1]));
             } else {
-                const floatx4 sel = t_hs ? tt[0] : tt[2];
-                *reinterpret_cast<floatx4*>(u + t_je) = sel * t_sg2 + tt[1];
+                put2(u + t_je, pk_fma(t_s2, tt[2][0], pk_fma(t_s0, tt[0][0], tt[1][0])),
+                     pk_fma(t_s2, tt[2][1], pk_fma(t_s0, tt[0][1], tt[1][1])));
             }
         }
     };
@@ -329,30 +361,41 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
 #pragma unroll
     for (int it = 0; it < kIters; ++it) {
         const int px = tid / (NCH / 4) + it * 16;
-        const int py = px / kOutW, pxx = px % kOutW;
+        const int py = px / kOutW, pxx = px % kOutW;          // = (it >> 1, p0 + 16 (it & 1)) or (it, p0)
         if (POOL == 0) vals[it] = staged(py, pxx);
         else if (POOL == 1) vals[it] = max4(max4(staged(2 * py, 2 * pxx), staged(2 * py, 2 * pxx + 1)), max4(staged(2 * py + 1, 2 * pxx), staged(2 * py + 1, 2 * pxx + 1)));
         else vals[it] = max4(staged(2 * py, pxx), staged(2 * py + 1, pxx));
     }
+    // A thread's pixels are p0 + 16 it: the same one or two columns in successive rows.  Column validity, the image a
+    // column belongs to and the column's share of the address are worked out once; the row's share is uniform.
+    constexpr int NJ = (kOutW == 32) ? 2 : 1;
+    const int p0 = tid / (NCH / 4);
+    bool col_ok[NJ];
+    int64_t col_idx[NJ];
 #pragma unroll
-    for (int it = 0; it < kIters; ++it) {
-        const int px = tid / (NCH / 4) + it * 16;
-        const int py = px / kOutW, pxx = px % kOutW;
-        const int yy = oy0 + py;
-        int xx = ox0 + pxx, ob = b;
+    for (int j = 0; j < NJ; ++j) {
+        int xx = ox0 + p0 + 16 * j, ob = b;
+        bool ok = true;
         if (a.vP > 0) {
             const int po = (POOL == 1) ? (a.vP >> 1) : a.vP;      // period of the images in output columns
             ob = xx / po;
             xx -= ob * po;
-            if (ob >= a.vB) continue;
+            ok = ob < a.vB;
         }
-        if (yy >= Ho || xx >= Wo) continue;
+        col_ok[j] = ok && xx < Wo;
+        col_idx[j] = ((int64_t)ob * Ho * Wo + xx) * a.cout + co0;
+    }
+    const int64_t row_stride = (int64_t)Wo * a.cout;
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const int py = (kOutW == 32) ? (it >> 1) : it, j = (kOutW == 32) ? (it & 1) : 0;
+        const int yy = oy0 + py;
+        if (yy >= Ho) break;                  // uniform
+        if (!col_ok[j]) continue;
         floatx4 val = vals[it] + bias4;
-        const int64_t idx = (((int64_t)ob * Ho + yy) * Wo + xx) * a.cout + co0;
+        const int64_t idx = col_idx[j] + yy * row_stride;
         if (vec_ok) {
-            if (POOL == 0 && a.res) {
-                val += *reinterpret_cast<const floatx4*>(a.res + idx);
-            }
+            if (POOL == 0 && a.res) val += *reinterpret_cast<const floatx4*>(a.res + idx);
             if (a.relu) {
                 val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
             }

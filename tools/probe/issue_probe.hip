@@ -17,6 +17,12 @@ __global__ __launch_bounds__(256, WPS) void probe(float* out, const float* src, 
     float a = a0 + threadIdx.x, b = b0;
     float x[4] = {a, b, a + 1.f, b + 1.f};
     floatx4 r[4];
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    floatx2 p2[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p2[i] = floatx2{a, b};
+    unsigned long long q2[4] = {1, 2, 3, 4};
+    unsigned iv = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = floatx4{a, b, a, b};
     for (int i = threadIdx.x; i < 256 * 16; i += 256) lds[i] = a;
@@ -35,12 +41,16 @@ __global__ __launch_bounds__(256, WPS) void probe(float* out, const float* src, 
                     if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(r[n & 3]) : "v"(laddr));
                     if (KIND == 3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[n & 3]) : "v"(gp));
                     if (KIND == 4) asm volatile("ds_write_b128 %0, %1" :: "v"(laddr), "v"(r[n & 3]));
+                    if (KIND == 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p2[n & 3]) : "v"(p2[4]), "v"(p2[5]));
+                    if (KIND == 6) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(p2[n & 3]) : "v"(p2[4]));
+                    if (KIND == 7) asm volatile("v_add_f32 %0, %1, %0" : "+v"(x[n & 3]) : "v"(a));
+                    if (KIND == 8) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q2[n & 3]) : "v"(iv), "v"(iv) : "vcc");
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
     }
-    float s = x[0] + x[1] + x[2] + x[3];
+    float s = x[0] + x[1] + x[2] + x[3] + p2[0][0] + p2[1][1] + p2[2][0] + p2[3][1] + (float)(q2[0] + q2[1] + q2[2] + q2[3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) s += r[i][0] + r[i][1] + r[i][2] + r[i][3];
 #pragma unroll
@@ -84,8 +94,9 @@ int main() {
     run<0, 0, 1>("mfma only");
     run<0, 0, 2>("mfma only");
     sweep<1>("valu fma");
-    sweep<2>("ds_read_b128");
-    sweep<4>("ds_write_b128");
-    sweep<3>("global b128");
+    sweep<7>("valu add");
+    sweep<5>("pk_fma_f32");
+    sweep<6>("pk_add_f32");
+    sweep<8>("mad_u64_u32");
     return 0;
 }
