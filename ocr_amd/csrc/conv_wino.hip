@@ -114,11 +114,7 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
     const int y0 = (tile / a.tiles_x) * 4, x0 = (tile % a.tiles_x) * 32;
     const int nK = a.cin / kCK;
 
-    floatx16 acc[8];
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[f][v] = 0.0f;
+    floatx16 acc[8];          // first written by the MFMAs of chunk 0, which take a literal zero as their addend
 
     // Global loads go through buffer descriptors: a per-lane 32-bit byte offset that never changes, the chunk as a
     // scalar offset, and the hardware's range check, which returns zeros for an offset beyond the buffer - the zero
@@ -263,8 +259,9 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
     // The loop is unrolled over the buffer parity, so every LDS address is a register that never changes plus an
     // immediate: between the MFMAs the vector ALU only does the transform's arithmetic (on this hardware every other
     // vector instruction delays the next MFMA by its own duration, even when a second wave has MFMAs ready).
-    auto chunk = [&](int kc, auto parity) {
+    auto chunk = [&](int kc, auto parity, auto first_chunk) {
         constexpr int P = decltype(parity)::value;
+        constexpr bool kFirst = decltype(first_chunk)::value;
         constexpr int ucur = P * kUFloats, unxt = (1 - P) * kUFloats;
         constexpr int rnxt = kR0 + (1 - P) * kRBuf, rfill = kR0 + P * kRBuf;
         const int kn = min(kc + 1, nK - 1);
@@ -281,7 +278,12 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
                     const float4 a4 = af[g][i], b4 = bw[f];
                     const float av = t == 0 ? a4.x : (t == 1 ? a4.y : (t == 2 ? a4.z : a4.w));
                     const float bv = t == 0 ? b4.x : (t == 1 ? b4.y : (t == 2 ? b4.z : b4.w));
-                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[f], 0, 0, 0);
+                    if (kFirst && t == 0) {
+                        const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, zero, 0, 0, 0);
+                    } else {
+                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[f], 0, 0, 0);
+                    }
                 }
                 if (g == 0) {
                     if (t < 2) {
@@ -306,9 +308,11 @@ __global__ __launch_bounds__(128 * CHB, CHB == 2 ? 2 : 1) void conv_wino_f32_ker
             }
         }
     };
-    for (int kc = 0; kc < nK; kc += 2) {        // nK is even
-        chunk(kc, std::integral_constant<int, 0>{});
-        chunk(kc + 1, std::integral_constant<int, 1>{});
+    chunk(0, std::integral_constant<int, 0>{}, std::true_type{});          // nK is even and at least 2
+    chunk(1, std::integral_constant<int, 1>{}, std::false_type{});
+    for (int kc = 2; kc < nK; kc += 2) {
+        chunk(kc, std::integral_constant<int, 0>{}, std::false_type{});
+        chunk(kc + 1, std::integral_constant<int, 1>{}, std::false_type{});
     }
 
     // ---- inverse transform.  Register v of a lane belongs to block m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5) of the
