@@ -1,0 +1,14 @@
+#!/bin/bash
+# Turns gpurun_out/prof (written by tools/collect_profiles.sh) into the files kept under profiles/<round>.
+#   bash tools/publish_profiles.sh r01
+set -e
+R=${1:-r01}
+P=gpurun_out/prof
+mkdir -p profiles/$R
+cp $P/trace/bench_kernel_stats.csv profiles/$R/bench_kernel_stats.csv
+tail -1 $P/bench_default.json.log > profiles/$R/bench_default.json.log
+python tools/pmc_traffic.py $P/fetch $P/write > profiles/pmc_traffic.json
+python tools/pmc_summary.py $P/fetch > profiles/$R/pmc_fetch_size.csv
+python tools/pmc_summary.py $P/write > profiles/$R/pmc_write_size.csv
+python tools/pmc_mfma.py $P/mfma > profiles/$R/pmc_mfma_util.csv
+python tools/profile_report.py profiles/$R > profiles/$R/kernel_report.md
