@@ -231,7 +231,8 @@ int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int 
  *   ocrhip_profile_collect: synchronises the device, aggregates the records per kernel name, writes
  *                           at most `cap` entries sorted by total time and sets *n to the number of
  *                           distinct kernels; flops / bytes are the ALGORITHMIC work of the launches
- *                           (see DESIGN.md), not counter readings. */
+ *                           (a direct convolution's 2*k*k*Cin*Cout flop per output pixel; bytes = inputs
+ *                           read once + outputs written once + weights), not counter readings. */
 typedef struct {
     char name[64];
     int launches;

@@ -6,7 +6,7 @@ utils/keras/runtimes/__init__.py:23-45); the object must look like
 `utils/keras/runtimes/runtime.py:19-42`: `__init__(path, *, engine=None, reload=False, **kw)`,
 `@staticmethod load_engine(path, **kw)`, `__call__(*args, **kwargs)`, class-level engine cache.
 `HIPRuntime` is that object for libocrhip.so; registering it is one line on the reference side
-(`_runtimes['hip'] = HIPRuntime`).
+(`_runtimes['hip'] = HIPRuntime` in utils/keras/runtimes/__init__.py).
 
 `BaseOCR.infer` / `BaseDetector.infer` call the runtime as `model(inputs, **kwargs)[0]` with extra
 keyword arguments (method=, num_beams=, ...) that a runtime must accept and ignore
