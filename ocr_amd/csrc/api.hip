@@ -533,9 +533,15 @@ int ocrhip_crnn_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n
             OCR_TRY(get(W, pre + ".rnn.weight_hh_l0" + suf, {4 * Hd, Hd}, &whh));
             OCR_TRY(get(W, pre + ".rnn.bias_ih_l0" + suf, {4 * Hd}, &bih));
             OCR_TRY(get(W, pre + ".rnn.bias_hh_l0" + suf, {4 * Hd}, &bhh));
-            std::vector<float> bsum(4 * Hd);
-            for (int i = 0; i < 4 * Hd; ++i) bsum[i] = bih[i] + bhh[i];
-            OCR_TRY(prepare_conv_mfma(net.wih[l][d], wih, bsum.data(), 4 * Hd, in_c, 1));
+            // rows of W_ih reordered from (gate, unit) to (unit, gate): the recurrence reads the four gate inputs of a unit
+            // as one 16-byte load
+            std::vector<float> bsum(4 * Hd), wperm((size_t)4 * Hd * in_c);
+            for (int gq = 0; gq < 4; ++gq)
+                for (int u = 0; u < Hd; ++u) {
+                    bsum[u * 4 + gq] = bih[gq * Hd + u] + bhh[gq * Hd + u];
+                    std::copy(wih + (size_t)(gq * Hd + u) * in_c, wih + (size_t)(gq * Hd + u + 1) * in_c, wperm.begin() + (size_t)(u * 4 + gq) * in_c);
+                }
+            OCR_TRY(prepare_conv_mfma(net.wih[l][d], wperm.data(), bsum.data(), 4 * Hd, in_c, 1));
             OCR_TRY(net.whh[l][d].reserve((size_t)4 * Hd * Hd * sizeof(float)));
             OCR_HIP_CHECK(hipMemcpy(net.whh[l][d].ptr, whh, (size_t)4 * Hd * Hd * sizeof(float), hipMemcpyHostToDevice));
         }
@@ -648,7 +654,7 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
     OCR_TRY(net.cbuf.reserve((size_t)2 * n * Hd * sizeof(float)));
     OCR_TRY(net.seq.reserve((size_t)R * 2 * Hd * sizeof(float)));
     OCR_TRY(net.lin.reserve((size_t)2 * R * Hd * sizeof(float)));
-    OCR_TRY(net.lstm_counters.reserve(2 * 16 * sizeof(unsigned)));
+    OCR_TRY(net.lstm_counters.reserve(kLstmCounterCount * sizeof(unsigned)));
     const float* layer_in = feats;
     for (int l = 0; l < 2; ++l) {
         float* xw_f = net.xw.as<float>();

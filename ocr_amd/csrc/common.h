@@ -216,7 +216,9 @@ int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, c
                      const int* seq_row0, int first, hipStream_t s);
 
 // rnn_persistent.hip: a whole bidirectional layer in one launch of persistent workgroups (hbuf: 2 parities x 2 directions x n x 256,
-// counters: 32 unsigned ints).  OCRHIP_ESTATE when the device cannot hold the grid at once (use the per-step kernel).
+// counters: kLstmCounterCount unsigned ints).  OCRHIP_ESTATE when the device cannot hold the grid at once or a workgroup
+// would need more passes than it has counters (use the per-step kernel).
+constexpr int kLstmCounterCount = 2 * 16 * 64;
 int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, float* hbuf, float* cbuf,
                       float* out, int n, int T, const int* seq_T, const int* seq_row0, const int* step_active,
                       unsigned* counters, hipStream_t s);

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict_
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 struct LstmArgs {
-    const float* xw[2];      // per direction (n, T, 1024), bias included
+    const float* xw[2];      // per direction (n, T, 1024), bias included; column = unit * 4 + gate
     const float* whh[2];     // per direction (1024, 256)
     const float* h_prev;     // (2, n, 256)
     float* h_next;           // (2, n, 256)
@@ -145,10 +145,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
             if (seq >= n) continue;
             const int Ts = a.seq_T ? a.seq_T[seq] : a.T;
             const int64_t row = (a.seq_row0 ? (int64_t)a.seq_row0[seq] : (int64_t)seq * a.T) + (dir ? (Ts - 1 - a.step) : a.step);
-            const float* xw = a.xw[dir] + row * (4 * kHidden) + u;
+            const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + row * (4 * kHidden) + u * 4);
+            const float xw[4] = {xw4.x, xw4.y, xw4.z, xw4.w};
             float z[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) z[g] = xw[g * kHidden] + gates[((g * 2 + r) * 16 + v) * 64 + lane];
+            for (int g = 0; g < 4; ++g) z[g] = xw[g] + gates[((g * 2 + r) * 16 + v) * 64 + lane];
             const int64_t sidx = ((int64_t)dir * n + seq) * kHidden + u;
             const float c_prev = (a.step > 0) ? a.c_state[sidx] : 0.0f;
             const float c = sigmoidf_(z[1]) * c_prev + sigmoidf_(z[0]) * tanhf(z[2]);

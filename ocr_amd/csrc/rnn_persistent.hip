@@ -5,17 +5,21 @@
 // architectures/crnn_arch.py:306-328 with Keras' cell equations and gate order i, f, c, o (rows i, f, g, o of the
 // torch checkpoint, models/weights_converter.py:305-314):
 //     z = xw_t + h_{t-1} W_hh^T ;  c = sig(z_f) c + sig(z_i) tanh(z_c) ;  h = sig(z_o) tanh(c)
-// with xw = x W_ih^T + (b_ih + b_hh) precomputed for all steps by the flat GEMM.
+// with xw = x W_ih^T + (b_ih + b_hh) precomputed for all steps by the flat GEMM, its columns ordered unit-major (the
+// four gates of a unit are one 16-byte load).
 //
 // Decomposition: workgroup = (direction, block of 32 hidden units, sequence group g of G).  It owns the 128 rows of W_hh
 // of its units (4 gates x 32 units x 256 k = 128 KB of LDS, 16-byte slots XOR-swizzled so that operand reads are
 // conflict free without padding) and every G-th sequence, longest first, so the sequences still running at step t are
-// a prefix of its rows and all groups shrink alike.  Per step it stages h_{t-1} of its sequences through LDS in k
-// chunks of 32, multiplies on v_mfma_f32_16x16x4_f32 (a wave = 8 units x 4 gates for all rows: up to 16 independent
-// accumulation chains), and finishes the cell in registers: the four gates of an element sit in two lanes (l, l ^ 8)
-// of one wave, exchanged by a lane permute.  The 8 workgroups that share (direction, g) hand h_t to each other
-// through global memory: h is stored and loaded with agent-scope atomic accesses and one atomic counter per
-// (direction, g) says when a step is complete.
+// a prefix of its rows and all groups shrink alike.  Its rows are worked off in passes of 112.  Per step and pass it
+// stages h_{t-1} of the pass's sequences through LDS in k chunks of 32 (double buffered, one barrier per chunk, the
+// global loads two chunks ahead), multiplies on v_mfma_f32_16x16x4_f32 (a wave = 8 units x 4 gates for all rows: up
+// to 14 independent accumulation chains; the code is specialised on the number of 16-row tiles so that the chunk
+// loop is branch free and the operand reads run ahead of the MFMAs), and finishes the cell in registers: the four
+// gates of an element sit in two lanes (l, l ^ 8) of one wave, exchanged by a lane permute.  The 8 workgroups that
+// share (direction, g) hand h_t to each other through global memory: h is stored and loaded with agent-scope atomic
+// accesses and one atomic counter per (direction, g, pass) says when a pass of a step is complete.  With two or more
+// passes the hand-over costs no waiting: the partners published pass p of step t-1 a pass ago.
 // Nothing else synchronises; a group whose sequences are all finished leaves.  The grid never exceeds what the device
 // holds at once (occupancy x CUs, checked by the launcher: the hand-over needs every workgroup resident); the spin
 // on the counter is bounded so that a lost partner can never hang the device: the wait gives up after ~1 s and the
@@ -33,13 +37,14 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kH = 256;            // hidden units
 constexpr int kRows = 112;         // sequences per pass of a workgroup (7 tiles of 16: what fits beside W_hh in 160 KB)
-constexpr int kKC = 64;            // k values per staged chunk of h
-constexpr int kAS = kKC + 4;       // floats per staged row of h
+constexpr int kKC = 32;            // k values per staged chunk of h
+constexpr int kAS = kKC + 4;       // floats per staged row of h (rows 144 bytes apart: conflict-free 16-byte reads)
 constexpr int kWFloats = 128 * kH; // W_hh slice
-constexpr int kLdsBytes = (kWFloats + kRows * kAS) * 4;
+constexpr int kLdsBytes = (kWFloats + 2 * kRows * kAS) * 4;
+constexpr int kMaxPass = 64;       // counters per (direction, group): passes a workgroup may need
 
 struct LayerArgs {
-    const float* xw[2];      // per direction (R, 1024), bias included
+    const float* xw[2];      // per direction (R, 1024), bias included; column = unit * 4 + gate
     const float* whh[2];     // per direction (1024, 256)
     float* hbuf;             // (2 parities, 2 directions, n, 256)
     float* cbuf;             // (2 directions, n, 256)
@@ -47,14 +52,26 @@ struct LayerArgs {
     const int* seq_T;        // time steps of each sequence, non-decreasing; nullptr: all T
     const int* seq_row0;     // first row of each sequence in the flat matrices; nullptr: s * T
     const int* step_active;  // sequences with more than t steps, per step t; nullptr: n
-    unsigned* counters;      // (2 directions, G), zero at launch
+    unsigned* counters;      // (2 directions x G, kMaxPass), zero at launch
     int n, T, G;
 };
 
-// logistic and tanh on the hardware exp2 / reciprocal (1 ulp each): the cell update of 14 elements per lane sits on
-// the critical path of every step
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// The cell update of 14 elements per lane sits on the critical path of every step, on a SIMD that runs one wave: what
+// counts is the number of instructions, the transcendental ones (quarter rate) above all.  Hardware exp2 and reciprocal
+// (1 ulp; __frcp_rn would be a ten-instruction division, __expf wraps v_exp_f32 in range scaling that 1 + e^x does
+// not need), and the products of logistic and tanh share a reciprocal:
+//     sig(a) tanh(b) = (1 - e^-2b) / ((1 + e^-a)(1 + e^-2b))        5 exp2 + 3 rcp per element instead of 5 + 5.
+// The exponents are capped at 2^60 so that the product of two denominators stays finite (sig(-41) is 1e-18 either way).
+__device__ __forceinline__ float exp2_capped(float x) { return __builtin_amdgcn_exp2f(fminf(x, 60.0f)); }
+__device__ __forceinline__ void lstm_cell(float zi, float zf, float zg, float zo, float cprev, float& c, float& h) {
+    const float ei = exp2_capped(-1.44269504f * zi), ef = exp2_capped(-1.44269504f * zf);
+    const float eg = exp2_capped(-2.88539008f * zg), eo = exp2_capped(-1.44269504f * zo);
+    const float sf = __builtin_amdgcn_rcpf(1.0f + ef);
+    const float ig = (1.0f - eg) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
+    c = sf * cprev + ig;
+    const float ec = exp2_capped(-2.88539008f * c);
+    h = (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + eo) * (1.0f + ec));
+}
 
 // h is the only data that moves between workgroups while the kernel runs.  It is written and read with relaxed
 // agent-scope atomic accesses: they go to the point where all CUs (of all XCDs) agree, so the hand-over needs no
@@ -70,10 +87,75 @@ __device__ __forceinline__ void store_h(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// acc += h_{t-1}[rows of the pass] (NT tiles of 16 rows) x W_hh^T[the wave's 32 gate rows], K = 256 in chunks of 32.
+// hoff[i]: offset of the float4 this thread stages for row srow + 32 i of the pass (-1: beyond the active rows).
+// `between` runs once the loads of the first two chunks are on their way (the requests for the cell update's operands:
+// their latency hides behind the GEMM, that of the first chunks behind their issue).
+template <int NT, class Between>
+__device__ __forceinline__ void gemm_pass(const float* __restrict__ hprev, const int64_t (&hoff)[4], const float* Ws, float* As,
+                                          int tid, int wave, int l16, int lg, floatx4 (&acc)[7][2], Between&& between) {
+    constexpr int kSweeps = (NT * 16 + 31) / 32;             // staging sweeps of 32 rows (8 lanes per row)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    float4 ra[2][kSweeps];
+    auto load_chunk = [&](int kc, int slot) {
+#pragma unroll
+        for (int i = 0; i < kSweeps; ++i)
+            ra[slot][i] = (hoff[i] >= 0) ? load_h4(hprev + hoff[i] + kc * kKC) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    load_chunk(0, 0);
+    load_chunk(1, 1);
+    between();
+#pragma unroll
+    for (int kc = 0; kc < kH / kKC; ++kc) {
+        float* buf = As + (kc & 1) * (kRows * kAS);
+        // the chunk's W_hh operands (static data: no need to wait for the barrier)
+        float4 b4[kKC / 16][2];
+#pragma unroll
+        for (int cbl = 0; cbl < kKC / 16; ++cbl) {               // 16 k values per block
+            const int c = (kc * (kKC / 16) + cbl) * 4 + lg;      // 16-byte slot of W_hh rows
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int R = wave * 32 + ct * 16 + l16;
+                b4[cbl][ct] = *reinterpret_cast<const float4*>(&Ws[(R * 64 + (c ^ (R & 15))) * 4]);
+            }
+        }
+        // buffer kc & 1 was last read for chunk kc - 2, i.e. before every wave's arrival at the barrier of chunk kc - 1
+#pragma unroll
+        for (int i = 0; i < kSweeps; ++i)
+            if (srow + i * 32 < kRows) *reinterpret_cast<float4*>(&buf[(srow + i * 32) * kAS + scol]) = ra[kc & 1][i];
+        __syncthreads();
+        if (kc + 2 < kH / kKC) load_chunk(kc + 2, kc & 1);
+        // (k block, row tile) items in sequence, the h operand of the next item requested before the MFMAs of this one
+        constexpr int kItems = (kKC / 16) * NT;
+        const float* arow = buf + l16 * kAS + lg * 4;
+        float4 a4[2];
+        a4[0] = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int cbl = it / NT, rt = it % NT;
+            if (it + 1 < kItems) {
+                const int cn = (it + 1) / NT, rn = (it + 1) % NT;
+                a4[(it + 1) & 1] = *reinterpret_cast<const float4*>(arow + rn * 16 * kAS + cn * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // keep the read ahead of the MFMAs (the scheduler sinks it)
+            const float4 av = a4[it & 1];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b4[cbl][ct].x, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b4[cbl][ct].y, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b4[cbl][ct].z, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b4[cbl][ct].w, acc[rt][ct], 0, 0, 0);
+        }
+    }
+}
+
+template <bool RAGGED>
 __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ws = lds;                 // [row R = wave*32 + gate*8 + unit8][64 slots of 16 bytes, slot c stored at c ^ (R & 15)]
-    float* As = lds + kWFloats;      // [row][kAS]
+    float* As = lds + kWFloats;      // [2 buffers][row][kAS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
     }
     const int dir = sg / G, g = sg % G;
     const int u0 = ub * 32;
-    unsigned* counter = a.counters + sg;
+    unsigned* counters = a.counters + sg * kMaxPass;
 
     // ---- W_hh slice -> LDS, once
     {
@@ -113,34 +195,47 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
 
     const int hi = (lane >> 3) & 1;
     const int unit = u0 + 8 * wave + (l16 & 7);
-    const int srow = tid >> 4, scol = (tid & 15) * 4;         // staging map: 16 lanes per row, 16 rows per sweep
 
-    // Everything a cell update needs besides h_{t-1} W_hh^T is fetched before the wait for h_{t-1}: the input
-    // projections xw of the lane's elements, their cell state and their row numbers.
+    // Everything a cell update needs besides h_{t-1} W_hh^T (the input projections xw of the lane's elements, their
+    // cell state and their row numbers) is requested right after the first loads of h_{t-1}, long before its use.
     float xwv[7][2][4], cpv[7][2];
     int rowv[7][2], sv[7][2];
-    auto prefetch_cells = [&](int t, int p, int rows_here) {
-        const int tiles_here = (rows_here + 15) >> 4;
+    // Branch free (elements beyond the active rows load sequence 0 and are ignored later): with a branch per element the
+    // compiler waits for each element's loads before it issues the next element's.  The sequence data (length, first
+    // row) that the addresses depend on are requested a pass ahead, so a pass pays one memory round trip, not two.
+    int Tsv[7][2], r0v[7][2];
+    auto prefetch_seq = [&](int p) {
 #pragma unroll
-        for (int rt = 0; rt < 7; ++rt) {
-            sv[rt][0] = -1;
-            sv[rt][1] = -1;
-            if (rt >= tiles_here) continue;
+        for (int rt = 0; rt < 7; ++rt)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int j = rt * 16 + 4 * lg + 2 * hi + k;
-                if (j >= rows_here) continue;
-                const int s = n - 1 - ((p * kRows + j) * G + g);
-                const int Ts = a.seq_T ? a.seq_T[s] : a.T;
-                const int row = (a.seq_row0 ? a.seq_row0[s] : s * a.T) + (dir ? (Ts - 1 - t) : t);
-                const float* xw = a.xw[dir] + (int64_t)row * (4 * kH) + unit;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) xwv[rt][k][gq] = xw[gq * kH];
-                cpv[rt][k] = (t > 0) ? a.cbuf[((int64_t)dir * n + s) * kH + unit] : 0.0f;
-                rowv[rt][k] = row;
-                sv[rt][k] = s;
+                const int s = max(n - 1 - ((p * kRows + j) * G + g), 0);
+                if (RAGGED) {
+                    Tsv[rt][k] = a.seq_T[s];
+                    r0v[rt][k] = a.seq_row0[s];
+                } else {
+                    Tsv[rt][k] = a.T;
+                    r0v[rt][k] = s * a.T;
+                }
             }
-        }
+    };
+    auto prefetch_cells = [&](int t, int p, int rows_here) {
+#pragma unroll
+        for (int rt = 0; rt < 7; ++rt)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int j = rt * 16 + 4 * lg + 2 * hi + k;
+                const bool on = j < rows_here;
+                const int s = max(n - 1 - ((p * kRows + j) * G + g), 0);
+                sv[rt][k] = on ? s : -1;
+                const int row = r0v[rt][k] + (dir ? (Tsv[rt][k] - 1 - t) : t);
+                const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)row * (4 * kH) + unit * 4);
+                xwv[rt][k][0] = xw4.x; xwv[rt][k][1] = xw4.y; xwv[rt][k][2] = xw4.z; xwv[rt][k][3] = xw4.w;
+                const float cprev = a.cbuf[((int64_t)dir * n + s) * kH + unit];
+                cpv[rt][k] = (t > 0) ? cprev : 0.0f;
+                rowv[rt][k] = row;
+            }
     };
 
     // cell state and layer output of the elements just finished (kept in cpv / xwv[.][.][0] by the cell update)
@@ -156,23 +251,11 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
             }
     };
 
+    prefetch_seq(0);
     for (int t = 0; t < a.T; ++t) {
-        const int n_act = a.step_active ? a.step_active[t] : n;              // sequences still running, over all groups
+        const int n_act = RAGGED ? a.step_active[t] : n;              // sequences still running, over all groups
         const int act_local = (n_act > g) ? (n_act - g + G - 1) / G : 0;      // prefix of this group's rows
         if (act_local == 0) break;
-        prefetch_cells(t, 0, min(kRows, act_local));
-        if (t > 0) {
-            // wait until the 8 workgroups of (direction, g) have published h_{t-1}
-            if (tid == 0) {
-                const unsigned want = 8u * (unsigned)t;
-                int spins = 0;
-                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1 << 22)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    ++spins;
-                }
-            }
-            __syncthreads();
-        }
         const float* hprev = a.hbuf + ((int64_t)((t + 1) & 1) * 2 + dir) * n * kH;
         float* hnext = a.hbuf + ((int64_t)(t & 1) * 2 + dir) * n * kH;
 
@@ -180,10 +263,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
             const int rows_here = min(kRows, act_local - p * kRows);         // active rows of this pass
             if (rows_here <= 0) break;
             const int tiles_here = (rows_here + 15) >> 4;
-            if (p > 0) {
-                flush_cells();
+            auto prefetch = [&]() {
                 prefetch_cells(t, p, rows_here);
-            }
+                prefetch_seq((p + 1 < n_pass && act_local > (p + 1) * kRows) ? p + 1 : 0);      // the pass that follows this one
+            };
 
             floatx4 acc[7][2];
 #pragma unroll
@@ -194,55 +277,35 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
                     for (int v = 0; v < 4; ++v) acc[rt][ct][v] = 0.0f;
 
             if (t > 0) {
-                int64_t hoff[7];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    const int j = srow + i * 16;
-                    const int d = (p * kRows + j) * G + g;
-                    hoff[i] = (j < rows_here) ? (int64_t)(n - 1 - d) * kH + scol : -1;
-                }
-                // the k chunks of h_{t-1} travel global -> registers -> LDS, two chunks ahead of their use
-                float4 ra[2][7];
-                auto load_chunk = [&](int kc, int slot) {
-#pragma unroll
-                    for (int i = 0; i < 7; ++i)
-                        ra[slot][i] = (hoff[i] >= 0) ? load_h4(hprev + hoff[i] + kc * kKC) : make_float4(0.f, 0.f, 0.f, 0.f);
-                };
-                load_chunk(0, 0);
-                load_chunk(1, 1);
-#pragma unroll
-                for (int kc = 0; kc < kH / kKC; ++kc) {
-                    __syncthreads();                                         // previous chunk fully read
-#pragma unroll
-                    for (int i = 0; i < 7; ++i) *reinterpret_cast<float4*>(&As[(srow + i * 16) * kAS + scol]) = ra[kc & 1][i];
-                    __syncthreads();
-                    if (kc + 2 < kH / kKC) load_chunk(kc + 2, kc & 1);
-#pragma unroll
-                    for (int cbl = 0; cbl < kKC / 16; ++cbl) {               // 16 k values per block
-                        const int c = (kc * (kKC / 16) + cbl) * 4 + lg;      // 16-byte slot of W_hh rows
-                        float4 b4[2];
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            const int R = wave * 32 + ct * 16 + l16;
-                            b4[ct] = *reinterpret_cast<const float4*>(&Ws[(R * 64 + (c ^ (R & 15))) * 4]);
-                        }
-#pragma unroll
-                        for (int rt = 0; rt < 7; ++rt) {
-                            if (rt < tiles_here) {
-                                const float4 a4 = *reinterpret_cast<const float4*>(&As[(rt * 16 + l16) * kAS + cbl * 16 + lg * 4]);
-#pragma unroll
-                                for (int ct = 0; ct < 2; ++ct) {
-                                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4[ct].x, acc[rt][ct], 0, 0, 0);
-                                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4[ct].y, acc[rt][ct], 0, 0, 0);
-                                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4[ct].z, acc[rt][ct], 0, 0, 0);
-                                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4[ct].w, acc[rt][ct], 0, 0, 0);
-                                }
-                            }
-                        }
+                // wait until the 8 workgroups of (direction, g) have published pass p of h_{t-1}
+                if (tid == 0) {
+                    const unsigned want = 8u * (unsigned)t;
+                    int spins = 0;
+                    while (__hip_atomic_load(counters + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1 << 22)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        ++spins;
                     }
                 }
+                __syncthreads();
+                int64_t hoff[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = (tid >> 3) + i * 32;
+                    const int d = (p * kRows + j) * G + g;
+                    hoff[i] = (j < rows_here) ? (int64_t)(n - 1 - d) * kH + (tid & 7) * 4 : -1;
+                }
+                switch (tiles_here) {
+                    case 1: gemm_pass<1>(hprev, hoff, Ws, As, tid, wave, l16, lg, acc, prefetch); break;
+                    case 2: gemm_pass<2>(hprev, hoff, Ws, As, tid, wave, l16, lg, acc, prefetch); break;
+                    case 3: gemm_pass<3>(hprev, hoff, Ws, As, tid, wave, l16, lg, acc, prefetch); break;
+                    case 4: gemm_pass<4>(hprev, hoff, Ws, As, tid, wave, l16, lg, acc, prefetch); break;
+                    case 5: gemm_pass<5>(hprev, hoff, Ws, As, tid, wave, l16, lg, acc, prefetch); break;
+                    case 6: gemm_pass<6>(hprev, hoff, Ws, As, tid, wave, l16, lg, acc, prefetch); break;
+                    default: gemm_pass<7>(hprev, hoff, Ws, As, tid, wave, l16, lg, acc, prefetch); break;
+                }
+            } else {
+                prefetch();
             }
-
             // ---- cell update.  Register v of tile (rt, ct) of a lane: row rt*16 + 4*lg + v, column l16 = (gate & 1) * 8 +
             // unit (ct 0: gates i, f; ct 1: gates g, o).  Lanes l and l ^ 8 hold the two halves of an element's gates: the
             // lane with bit 3 clear finishes rows v = 0, 1, its partner rows v = 2, 3.
@@ -251,43 +314,53 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
                 if (rt >= tiles_here) continue;
                 float mine[2][2], theirs[2][2];          // [ct][row of my pair]
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < 2; ++ct) {
+                    float v0 = acc[rt][ct][0], v1 = acc[rt][ct][1], v2 = acc[rt][ct][2], v3 = acc[rt][ct][3];
+                    // opaque to the optimiser, which otherwise turns the selects below into a dynamic register index
+                    // (three selects each)
+                    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+                    const float lo[2] = {v0, v1}, up[2] = {v2, v3};
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        const float keep = hi ? acc[rt][ct][2 + k] : acc[rt][ct][k];
-                        const float send = hi ? acc[rt][ct][k] : acc[rt][ct][2 + k];
-                        mine[ct][k] = keep;
-                        theirs[ct][k] = __shfl_xor(send, 8, 64);
+                        mine[ct][k] = hi ? up[k] : lo[k];
+                        const float send = hi ? lo[k] : up[k];
+                        // lane l ^ 8 = rotation by 8 within the row of 16 lanes: a DPP move, no LDS round trip
+                        theirs[ct][k] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xF, 0xF, false));
                     }
+                }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int s = sv[rt][k];
-                    if (s < 0) continue;
                     // my column holds gate (i or g) when hi == 0 and (f or o) when hi == 1
                     const float zi = xwv[rt][k][0] + (hi ? theirs[0][k] : mine[0][k]);
                     const float zf = xwv[rt][k][1] + (hi ? mine[0][k] : theirs[0][k]);
                     const float zg = xwv[rt][k][2] + (hi ? theirs[1][k] : mine[1][k]);
                     const float zo = xwv[rt][k][3] + (hi ? mine[1][k] : theirs[1][k]);
-                    const float c = sigmoidf_(zf) * cpv[rt][k] + sigmoidf_(zi) * tanhf_(zg);
-                    const float hval = sigmoidf_(zo) * tanhf_(c);
-                    store_h(hnext + (int64_t)s * kH + unit, hval);
+                    float c, hval;
+                    lstm_cell(zi, zf, zg, zo, cpv[rt][k], c, hval);
                     cpv[rt][k] = c;                  // written out, with the layer output, after h_t is published
                     xwv[rt][k][0] = hval;
                 }
             }
+            // the stores apart from the arithmetic: a branch per element in there would serialise the elements' chains of
+            // dependent transcendental instructions
+#pragma unroll
+            for (int rt = 0; rt < 7; ++rt)
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (sv[rt][k] >= 0) store_h(hnext + (int64_t)sv[rt][k] * kH + unit, xwv[rt][k][0]);
+            // publish pass p of h_t, then write what only this workgroup reads again
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): this thread's h stores have reached the coherence point
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(counters + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flush_cells();
         }
-        // publish h_t, then write what only this workgroup reads again
-        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this thread's h stores have reached the coherence point
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flush_cells();
     }
 }
 
 }  // namespace
 
-// One bidirectional LSTM layer over n sequences in one launch of persistent workgroups.  `counters` must hold 2 * 16 unsigned
-// ints (they are cleared here).  Returns OCRHIP_ESTATE when the device cannot hold the grid at once; the caller then
+// One bidirectional LSTM layer over n sequences in one launch of persistent workgroups.  `counters` must hold
+// kLstmCounterCount unsigned ints (they are cleared here).  Returns OCRHIP_ESTATE when the device cannot hold the grid at once; the caller then
 // uses the per-step kernel.
 int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, float* hbuf, float* cbuf,
                       float* out, int n, int T, const int* seq_T, const int* seq_row0, const int* step_active,
@@ -301,11 +374,12 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
     OCR_HIP_CHECK(hipGetDevice(&dev));
     int& mg = max_groups[dev & 63];
     if (mg == 0) {
-        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         hipDeviceProp_t prop;
         OCR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         int per_cu = 0;
-        OCR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_layer_kernel), 256, kLdsBytes));
+        OCR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_layer_kernel<true>), 256, kLdsBytes));
         const int resident = per_cu * prop.multiProcessorCount;
         mg = (resident >= 16) ? std::min(16, resident / 16) : -1;
     }
@@ -318,10 +392,18 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
     a.hbuf = hbuf; a.cbuf = cbuf; a.out = out; a.seq_T = seq_T; a.seq_row0 = seq_row0; a.step_active = step_active;
     a.counters = counters; a.n = n; a.T = T;
     a.G = std::max(1, std::min(mg, (n + 15) / 16));          // no more groups than 16-row tiles of work
-    OCR_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * 16 * sizeof(unsigned), s));
+    if (((n + a.G - 1) / a.G + kRows - 1) / kRows > kMaxPass) {
+        set_error("lstm_layer: more passes per workgroup than counters (n=%d)", n);
+        return OCRHIP_ESTATE;
+    }
+    static_assert(kLstmCounterCount == 2 * 16 * kMaxPass, "counter buffer size");
+    OCR_HIP_CHECK(hipMemsetAsync(counters, 0, kLstmCounterCount * sizeof(unsigned), s));
     // a plain launch: the grid is sized to what the device holds at once (checked above), which is all the hand-over
     // needs; the cooperative-launch entry point, which performs the same check, crashes the profiler at process exit
-    hipLaunchKernelGGL(lstm_layer_kernel, dim3(16 * a.G), dim3(256), kLdsBytes, s, a);
+    if (seq_T)
+        hipLaunchKernelGGL(lstm_layer_kernel<true>, dim3(16 * a.G), dim3(256), kLdsBytes, s, a);
+    else
+        hipLaunchKernelGGL(lstm_layer_kernel<false>, dim3(16 * a.G), dim3(256), kLdsBytes, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }
