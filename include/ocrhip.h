@@ -66,7 +66,10 @@ int ocrhip_destroy(ocrhip_handle h);
  *   F(2x2,3x3) in float32 (2.25x fewer multiplications, results within float32 rounding of the direct sum);
  *   0 computes them as a direct implicit GEMM (a float32 fma chain over the taps and channels).
  *   "lstm_persistent": 1 (default) runs the recurrence of a BiLSTM layer as one launch of persistent workgroups
- *   (W_hh resident in LDS, h_t handed over through L2); 0 launches one kernel per time step.  Same arithmetic. */
+ *   (W_hh resident in LDS, h_t handed over through L2); 0 launches one kernel per time step.  Same arithmetic.
+ *   "flat_gemm": 1 (default) runs the Dense layers, the LSTM input projections and the 2x2 convolutions as a flat
+ *   GEMM with 256 x 128 tiles; 0 runs them on the implicit-GEMM convolution kernel (256 x 64 / spatial tiles).  Same
+ *   arithmetic (a float32 fma chain over k in both). */
 int ocrhip_set_option(ocrhip_handle h, const char* name, int value);
 
 /* ------------------------------------------------------------------------------------ EAST --

@@ -37,6 +37,9 @@ void set_lstm_persistent(int on) { g_lstm_persistent = on; }
 static thread_local int g_conv3x3_winograd = 1;
 int conv3x3_winograd() { return g_conv3x3_winograd; }
 void set_conv3x3_winograd(int on) { g_conv3x3_winograd = on; }
+static thread_local int g_flat_gemm = 1;
+int flat_gemm() { return g_flat_gemm; }
+void set_flat_gemm(int on) { g_flat_gemm = on; }
 
 hipEvent_t Profiler::get_event() {
     if (!pool.empty()) {
@@ -238,6 +241,7 @@ using namespace ocrhip;
         ocrhip::set_current_profiler(&(h)->prof);                   \
         ocrhip::set_conv3x3_winograd((h)->conv3x3_winograd);        \
         ocrhip::set_lstm_persistent((h)->lstm_persistent);          \
+        ocrhip::set_flat_gemm((h)->flat_gemm);                      \
     } while (0)
 
 extern "C" {
@@ -268,7 +272,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     if (!h) return OCRHIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.w_bf16.release(); L.bias.release(); };
+    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.w_bf16.release(); L.bias.release(); L.w_gemm.release(); L.bias_gemm.release(); };
     for (auto& L : h->crnn.rconv) free_layer(L);
     for (auto& L : h->east.vgg) free_layer(L);
     for (auto& L : h->east.merge) free_layer(L);
@@ -818,6 +822,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "lstm_persistent") == 0) {
         OCR_REQUIRE(value == 0 || value == 1, "set_option: lstm_persistent is 0 or 1");
         h->lstm_persistent = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "flat_gemm") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: flat_gemm is 0 or 1");
+        h->flat_gemm = value;
         return OCRHIP_OK;
     }
     set_error("set_option: unknown option '%s'", name);

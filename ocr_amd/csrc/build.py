@@ -31,6 +31,7 @@ SOURCES = {
     'ctc.hip': ['-ffp-contract=off'],
     'conv_direct.hip': [],
     'conv_mfma.hip': [],
+    'gemm_f32.hip': [],
     'conv_wino.hip': ['-fno-slp-vectorize'],
     'conv_bf16.hip': [],
     'rnn.hip': [],

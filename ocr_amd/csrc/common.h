@@ -95,6 +95,7 @@ struct ConvLayer {
     DevBuf w_bf16;          // bfloat16 slab of the same layer (see conv_bf16.hip), when cin % 16 == 0
     DevBuf w_wino;          // 3x3 layers with >= 64 output channels: Winograd-transformed filters (see conv_wino.hip)
     DevBuf bias;            // cout_pad floats, folded
+    DevBuf w_gemm, bias_gemm;   // 1x1 and 2x2 layers: slabs and bias for the 256 x 128 flat GEMM (see gemm_f32.hip)
     bool direct = false;    // small-Cin direct kernel layout
 };
 
@@ -147,6 +148,7 @@ struct ocrhip_ctx {
     ocrhip::DevBuf lanms_ws;       // scratch of the LANMS kernel
     int lstm_persistent = 1;       // recurrence of a BiLSTM layer in one persistent launch (1) or one launch per step (0)
     int conv3x3_winograd = 1;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
+    int flat_gemm = 1;             // 1x1 / 2x2 layers on the 256 x 128 flat GEMM (1) or on the implicit-GEMM convolution kernel (0)
     ocrhip::Profiler prof;
 };
 
@@ -179,6 +181,13 @@ int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H,
                      const float* residual, hipStream_t s);
 int conv3x3_winograd();              // option of the handle in use on this thread
 void set_conv3x3_winograd(int on);
+
+// gemm_f32.hip: 1x1 and 2x2 layers as a flat GEMM with segmented A rows; launch_conv_mfma forwards to it when the
+// handle's "flat_gemm" option is on (the default) and the layer has neither pooling, upsampling nor a residual.
+int prepare_gemm_f32(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);
+int launch_gemm_f32(const ConvLayer& L, const float* x, float* y, int B, int H, int W, bool relu, hipStream_t s);
+int flat_gemm();                     // option of the handle in use on this thread
+void set_flat_gemm(int on);
 
 // conv_direct.hip: first layers (Cin 3 or 1) and the 32->6 sigmoid heads.
 int prepare_conv_direct(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);

@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
             for (int v = 0; v < 16; ++v) acc[r][nt][v] = 0.0f;
 
     const float* wslab = a.w + (int64_t)nb * nK * B_FLOATS;
+    // bias now: a load still in flight in the epilogue would make every guarded store wait for the one before it
+    float biasv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) biasv[nt] = a.bias[nb * BN + nt * 32 + li];          // bias is padded to cout_pad
 
     // Software pipeline over the K chunks: the global loads of chunk k+1 are issued into registers
     // before the matrix work of chunk k and written to LDS after it, so their latency hides behind
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nb * BN + nt * 32 + li;
         const bool co_ok = co < a.cout;
-        const float bias = a.bias[co];          // bias is padded to cout_pad
+        const float bias = biasv[nt];
         if (KS == 1) {
 #pragma unroll
             for (int r = 0; r < MT; ++r)
@@ -394,6 +398,7 @@ int prepare_conv_mfma(ConvLayer& L, const float* w_oihw, const float* bias, int 
     OCR_HIP_CHECK(hipMemcpy(L.bias.ptr, bpad.data(), bpad.size() * sizeof(float), hipMemcpyHostToDevice));
     if (ks == 3 && BN == 64 && cin % 16 == 0) OCR_TRY(prepare_conv_wino(L, w_oihw, cout, cin));
     if (cin % 16 == 0) OCR_TRY(prepare_conv_bf16(L, w_oihw, cout, cin, ks));
+    if (ks != 3 && cin % 16 == 0) OCR_TRY(prepare_gemm_f32(L, w_oihw, bias, cout, cin, ks));
     return OCRHIP_OK;
 }
 
@@ -405,6 +410,7 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
     if (compute_bf16()) return launch_conv_bf16(L, x, y, B, H, W, pool, relu, up_src, up_c, s, residual);
     if (ks == 3 && L.w_wino.ptr && !up_src && conv3x3_winograd() && (int64_t)H * W * L.cin * 4 < (1ll << 31))
         return launch_conv_wino(L, x, y, B, H, W, pool, relu, residual, s);
+    if (ks != 3 && L.w_gemm.ptr && !up_src && !residual && pool == 0 && flat_gemm()) return launch_gemm_f32(L, x, y, B, H, W, relu, s);
     const int BN = (L.cout_pad % 64 == 0) ? 64 : 32;
     const int NT = BN / 32;
     ConvArgs a;

@@ -1,0 +1,228 @@
+// Flat GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32): y[M, N] = act(A[M, K] W[N, K]^T + bias).
+//
+// Carries the contractions of the recogniser that have no spatial reuse to exploit: the LSTM input projections and
+// the Dense layers of architectures/crnn_arch.py:306-328,517-519 (K = 256 or 512, N = 2048 / 256 / vocabulary) and
+// its 2x2 VALID convolutions (crnn_arch.py:38-41: the last layer of the VGG extractor; crnn_arch.py:330-425: conv4_1 /
+// conv4_2 of the ResNet one).  A 2x2 convolution over NHWC data is a GEMM whose A row is not one contiguous run but
+// KS runs: output pixel (b, r, c) reads, for each kernel row dy, the 2 * Cin floats that start at input pixel
+// (b, r + dy, c).  The kernel therefore addresses A as `row base + segment(k)`: K is cut into segments of `seg_len`
+// floats that lie `seg_stride` floats apart (one segment for a plain GEMM), and the row base is any function of the
+// row number (here: the pixel's offset).  No im2col copy, no half-empty spatial tile: every row of the 256-row M
+// tile is a real output pixel.
+//
+// Same arithmetic as conv_mfma.hip (exact float32 products accumulated in float32 in k order); what differs is the
+// blocking: a workgroup (4 waves) owns 256 rows x 128 columns (a wave 64 x 128: 8 accumulator tiles, so an A operand
+// is reused by 4 MFMAs and a B operand by 2), K runs in chunks of 16 through a double-buffered LDS image (one barrier
+// per chunk, the global loads of chunk k + 1 issued before the MFMAs of chunk k), and two workgroups share a CU.
+//
+// Roofline: MFMA bound (2 M N K flop against 64 flop/clk/SIMD).
+#include <type_traits>
+
+#include "common.h"
+
+namespace ocrhip {
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 256, kBN = 128, kCK = 16, kPS = kCK + 4;
+constexpr int kAFloats = kBM * kPS, kBFloats = kCK * kBN;
+
+struct GemmArgs {
+    const float* x;
+    const float* w;          // slabs [n block][k chunk][q][h][128 columns][4]: k = chunk * 16 + 8 q + 4 h + t
+    const float* bias;       // n_pad floats
+    float* y;                // (M, N)
+    int64_t M;
+    int N, K, relu;
+    int n_blocks;
+    // A addressing: row m = (b * Hc + r) * Wc + c  ->  base ((b * H + r) * W + c) * cin; k -> (k / seg_len) * seg_stride + k % seg_len
+    int Hc, Wc, H, W, cin;
+    int seg_len, seg_stride;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2][kAFloats];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kBFloats];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    // every XCD (own L2) walks one contiguous range of the work index, in which the column blocks of an M tile are
+    // adjacent: the A tile is fetched from HBM once
+    const unsigned total = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned work = xcd * (total >> 3) + min(xcd, total & 7u) + slot;
+    const int nb = (int)(work % (unsigned)a.n_blocks);
+    const int64_t m0 = (int64_t)(work / (unsigned)a.n_blocks) * kBM;
+    const int nK = a.K / kCK;
+
+    // the 4 rows this thread stages (row = tid / 4 + 64 i, 16-byte column tid % 4)
+    int64_t abase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + (tid >> 2) + 64 * i;
+        if (m < a.M) {
+            const int c = (int)(m % a.Wc);
+            const int64_t br = m / a.Wc;
+            const int r = (int)(br % a.Hc);
+            const int64_t b = br / a.Hc;
+            abase[i] = (((b * a.H + r) * a.W) + c) * (int64_t)a.cin + (tid & 3) * 4;
+        } else {
+            abase[i] = -1;
+        }
+    }
+    const float* wslab = a.w + (int64_t)nb * nK * kBFloats;
+
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][nt][v] = 0.0f;
+
+    // bias now: a load still in flight in the epilogue would make every guarded store wait for the one before it
+    float biasv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) biasv[nt] = a.bias[nb * kBN + nt * 32 + li];
+
+    // (scalars, not a two-element array: the compiler moves such an array to LDS, i.e. waits for the load at once)
+    float4 ra[4], rb0, rb1;
+    auto load_chunk = [&](int kc) {
+        const float4* src = reinterpret_cast<const float4*>(wslab + (int64_t)kc * kBFloats);
+        rb0 = src[tid];
+        rb1 = src[tid + 256];
+        const int k0 = kc * kCK;
+        const int64_t koff = (int64_t)(k0 / a.seg_len) * a.seg_stride + k0 % a.seg_len;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ra[i] = (abase[i] >= 0) ? *reinterpret_cast<const float4*>(a.x + abase[i] + koff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_chunk = [&](int buf) {
+        reinterpret_cast<float4*>(Bs[buf])[tid] = rb0;
+        reinterpret_cast<float4*>(Bs[buf])[tid + 256] = rb1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[buf][((tid >> 2) + 64 * i) * kPS + (tid & 3) * 4]) = ra[i];
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    for (int kc = 0; kc < nK; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nK) load_chunk(kc + 1);
+#pragma unroll
+        for (int q = 0; q < kCK / 8; ++q) {
+            float av[2][4], bv[4][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&As[buf][(wave * 64 + r * 32 + li) * kPS + q * 8 + lh * 4]);
+                av[r][0] = t4.x; av[r][1] = t4.y; av[r][2] = t4.z; av[r][3] = t4.w;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&Bs[buf][(((q * 2 + lh) * kBN) + nt * 32 + li) * 4]);
+                bv[nt][0] = t4.x; bv[nt][1] = t4.y; bv[nt][2] = t4.z; bv[nt][3] = t4.w;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[r][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r][t], bv[nt][t], acc[r][nt], 0, 0, 0);
+        }
+        // the LDS writes below stay behind the MFMAs, and the latency of the loads with them (left alone the compiler
+        // merges the two `kc + 1 < nK` regions and writes the weight slab to LDS right after loading it)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 1 < nK) {
+            // the other buffer was last read for chunk kc - 1, before every wave's arrival at the previous barrier
+            store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // accumulator register v of a lane: row (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5) of its 32-row tile, column lane & 31
+    const bool full = (m0 + kBM <= a.M) && ((nb + 1) * kBN <= a.N);      // uniform: no guards on the stores
+    auto write_out = [&](auto guarded) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int co = nb * kBN + nt * 32 + li;
+            const bool co_ok = co < a.N;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int64_t mrow = m0 + wave * 64 + r * 32 + 4 * lh;
+                float* yrow = a.y + mrow * a.N + co;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int dm = (v & 3) + 8 * (v >> 2);
+                    float o = acc[r][nt][v] + biasv[nt];
+                    if (a.relu) o = fmaxf(o, 0.0f);
+                    if (!decltype(guarded)::value || (co_ok && mrow + dm < a.M)) yrow[(int64_t)dm * a.N] = o;
+                }
+            }
+        }
+    };
+    if (full)
+        write_out(std::false_type{});
+    else
+        write_out(std::true_type{});
+}
+
+}  // namespace
+
+// Weights (cout, cin, ks, ks) of a 1x1 or 2x2 layer -> the GEMM's slabs.  GEMM k = (ky * ks + kx) * cin + c: the order
+// in which an NHWC input row pair lies in memory.
+int prepare_gemm_f32(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks) {
+    OCR_REQUIRE(ks == 1 || ks == 2, "gemm_f32: kernel size %d not supported", ks);
+    const int K = ks * ks * cin;
+    OCR_REQUIRE(cin % kCK == 0, "gemm_f32: cin=%d must be a multiple of %d", cin, kCK);
+    const int nN = (cout + kBN - 1) / kBN, nK = K / kCK, taps = ks * ks;
+    std::vector<float> w((size_t)nN * nK * kBFloats, 0.0f), bpad((size_t)nN * kBN, 0.0f);
+    for (int o = 0; o < cout; ++o) {
+        if (bias) bpad[o] = bias[o];
+        for (int k = 0; k < K; ++k) {
+            const int tap = k / cin, c = k % cin;
+            const int kc = k / kCK, q = (k % kCK) / 8, hh = (k % 8) / 4, t = k % 4;
+            const size_t dst = ((((size_t)(o / kBN) * nK + kc) * (kCK / 8) + q) * 2 + hh) * kBN * 4 + (size_t)(o % kBN) * 4 + t;
+            w[dst] = w_oihw[((size_t)o * cin + c) * taps + tap];
+        }
+    }
+    OCR_TRY(L.w_gemm.reserve(w.size() * sizeof(float)));
+    OCR_TRY(L.bias_gemm.reserve(bpad.size() * sizeof(float)));
+    OCR_HIP_CHECK(hipMemcpy(L.w_gemm.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    OCR_HIP_CHECK(hipMemcpy(L.bias_gemm.ptr, bpad.data(), bpad.size() * sizeof(float), hipMemcpyHostToDevice));
+    return OCRHIP_OK;
+}
+
+// x: (B, H, W, cin) NHWC; y: (B, H - ks + 1, W - ks + 1, cout).  ks == 1 is the flat GEMM over B * H * W rows.
+int launch_gemm_f32(const ConvLayer& L, const float* x, float* y, int B, int H, int W, bool relu, hipStream_t s) {
+    OCR_REQUIRE(L.w_gemm.ptr && (L.ks == 1 || L.ks == 2), "gemm_f32: layer not prepared");
+    OCR_REQUIRE(x && y && B > 0 && H >= L.ks && W >= L.ks, "gemm_f32: bad arguments B=%d H=%d W=%d", B, H, W);
+    GemmArgs a;
+    a.x = x; a.w = L.w_gemm.as<float>(); a.bias = L.bias_gemm.as<float>(); a.y = y;
+    a.N = L.cout; a.K = L.ks * L.ks * L.cin; a.relu = relu ? 1 : 0;
+    a.n_blocks = (L.cout + kBN - 1) / kBN;
+    a.H = H; a.W = W; a.cin = L.cin;
+    a.Hc = H - L.ks + 1; a.Wc = W - L.ks + 1;
+    a.M = (int64_t)B * a.Hc * a.Wc;
+    a.seg_len = L.ks * L.cin;             // one kernel row: ks pixels of cin channels, contiguous in NHWC
+    a.seg_stride = W * L.cin;
+    OCR_REQUIRE((int64_t)B * H * W * L.cin < (1ll << 40), "gemm_f32: input too large");
+    const int64_t wgs = (a.M + kBM - 1) / kBM * a.n_blocks;
+    OCR_REQUIRE(wgs < (1ll << 31), "gemm_f32: too many workgroups");
+    char pname[64];
+    std::snprintf(pname, sizeof(pname), "gemm_f32<ks%d,tile256x128>", L.ks);
+    ProfScope prof(pname, 2.0 * (double)a.M * a.N * a.K,
+                   4.0 * ((double)B * H * W * L.cin + (double)a.M * a.N + (double)a.N * a.K), s);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, s, a);
+    OCR_HIP_CHECK(hipGetLastError());
+    return OCRHIP_OK;
+}
+
+}  // namespace ocrhip

@@ -92,7 +92,9 @@ class HipContext:
 
     def set_option(self, name, value):
         """'conv3x3_winograd': 1 (default) Winograd F(2x2,3x3) for the wide 3x3 convolutions, 0 direct implicit GEMM.
-        'lstm_persistent': 1 (default) one persistent launch per BiLSTM layer, 0 one launch per time step."""
+        'lstm_persistent': 1 (default) one persistent launch per BiLSTM layer, 0 one launch per time step.
+        'flat_gemm': 1 (default) Dense layers / LSTM input projections / 2x2 convolutions on the 256 x 128 flat GEMM,
+        0 on the implicit-GEMM convolution kernel."""
         check(self.lib.ocrhip_set_option(self._h, name.encode(), int(value)))
 
     def image_resize_norm(self, images, out_h, out_w):

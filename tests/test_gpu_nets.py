@@ -188,6 +188,29 @@ def test_lstm_per_step_launches_match_the_persistent_layer(ctx):
     np.testing.assert_array_equal(a['lengths'].cpu().numpy(), b['lengths'].cpu().numpy())
 
 
+def test_flat_gemm_matches_the_convolution_kernel(ctx):
+    """`flat_gemm = 0` runs the Dense layers, the LSTM input projections and the 2x2 convolutions on the implicit-GEMM
+    convolution kernel instead of the 256 x 128 flat GEMM.  Both are float32 fma chains; the 2x2 layers sum taps and
+    channels in a different order (tap-major here, channel-chunk-major there), so the logits agree to float32
+    rounding, not bit for bit (VGG and ResNet extractors, ragged widths)."""
+    rng = np.random.default_rng(9)
+    widths = np.array([64] * 3 + [96] * 7 + [128] * 5 + [320], dtype=np.int32)
+    packed = torch.from_numpy(rng.uniform(-1, 1, int(64 * widths.sum())).astype(np.float32)).cuda()
+    try:
+        for backbone in ('vgg', 'resnet'):
+            ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=97, seed=13, backbone=backbone))
+            a = ctx.crnn_forward_packed(packed, widths, want_logits=True)['logits'].cpu().numpy()
+            ctx.set_option('flat_gemm', 0)
+            try:
+                b = ctx.crnn_forward_packed(packed, widths, want_logits=True)['logits'].cpu().numpy()
+            finally:
+                ctx.set_option('flat_gemm', 1)
+            assert np.isfinite(a).all()
+            _close(a, b, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(b).max())))
+    finally:
+        ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=97, seed=2))
+
+
 def test_bf16_variant_within_1e2_of_the_float32_oracle(ctx):
     """`compute_dtype = BF16`: bfloat16 operands, float32 accumulation.  Tolerance: relative error of the whole tensor
     ||got - ref|| / ||ref|| <= 1e-2 against the float32 oracle, and no single element further than 5e-2 of the tensor's
