@@ -272,7 +272,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     if (!h) return OCRHIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.w_bf16.release(); L.bias.release(); L.w_gemm.release(); L.bias_gemm.release(); };
+    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.w_wino4.release(); L.w_bf16.release(); L.bias.release(); L.w_gemm.release(); L.bias_gemm.release(); };
     for (auto& L : h->crnn.rconv) free_layer(L);
     for (auto& L : h->east.vgg) free_layer(L);
     for (auto& L : h->east.merge) free_layer(L);
@@ -815,7 +815,7 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     OCR_HANDLE(h);
     OCR_REQUIRE(name, "set_option: null name");
     if (std::strcmp(name, "conv3x3_winograd") == 0) {
-        OCR_REQUIRE(value == 0 || value == 1, "set_option: conv3x3_winograd is 0 or 1");
+        OCR_REQUIRE(value >= 0 && value <= 2, "set_option: conv3x3_winograd is 0, 1 or 2");
         h->conv3x3_winograd = value;
         return OCRHIP_OK;
     }

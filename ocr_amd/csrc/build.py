@@ -33,6 +33,7 @@ SOURCES = {
     'conv_mfma.hip': [],
     'gemm_f32.hip': [],
     'conv_wino.hip': ['-fno-slp-vectorize'],
+    'conv_wino4.hip': [],
     'conv_bf16.hip': [],
     'rnn.hip': [],
     'rnn_persistent.hip': [],

@@ -94,6 +94,7 @@ struct ConvLayer {
     DevBuf w_f32;           // MFMA slab layout (see conv_mfma.hip) or direct layout (see conv_direct.hip)
     DevBuf w_bf16;          // bfloat16 slab of the same layer (see conv_bf16.hip), when cin % 16 == 0
     DevBuf w_wino;          // 3x3 layers with >= 64 output channels: Winograd-transformed filters (see conv_wino.hip)
+    DevBuf w_wino4;         // the same layers: F(4x4,3x3)-transformed filters (see conv_wino4.hip)
     DevBuf bias;            // cout_pad floats, folded
     DevBuf w_gemm, bias_gemm;   // 1x1 and 2x2 layers: slabs and bias for the 256 x 128 flat GEMM (see gemm_f32.hip)
     bool direct = false;    // small-Cin direct kernel layout
@@ -179,6 +180,11 @@ void set_compute_bf16(int on);
 int prepare_conv_wino(ConvLayer& L, const float* w_oihw, int cout, int cin);
 int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
                      const float* residual, hipStream_t s);
+// conv_wino4.hip: F(4x4,3x3) for the launches whose maps fill its 16 x 32 tiles (option "conv3x3_winograd" = 2)
+int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin);
+bool conv_wino4_fits(const ConvLayer& L, int H, int W, int pool);
+int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
+                      const float* residual, hipStream_t s);
 int conv3x3_winograd();              // option of the handle in use on this thread
 void set_conv3x3_winograd(int on);
 

@@ -397,6 +397,7 @@ int prepare_conv_mfma(ConvLayer& L, const float* w_oihw, const float* bias, int 
     OCR_HIP_CHECK(hipMemcpy(L.w_f32.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     OCR_HIP_CHECK(hipMemcpy(L.bias.ptr, bpad.data(), bpad.size() * sizeof(float), hipMemcpyHostToDevice));
     if (ks == 3 && BN == 64 && cin % 16 == 0) OCR_TRY(prepare_conv_wino(L, w_oihw, cout, cin));
+    if (ks == 3 && BN == 64 && cin % 16 == 0) OCR_TRY(prepare_conv_wino4(L, w_oihw, cout, cin));
     if (cin % 16 == 0) OCR_TRY(prepare_conv_bf16(L, w_oihw, cout, cin, ks));
     if (ks != 3 && cin % 16 == 0) OCR_TRY(prepare_gemm_f32(L, w_oihw, bias, cout, cin, ks));
     return OCRHIP_OK;
@@ -408,6 +409,8 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
     OCR_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "conv_mfma: bad arguments B=%d H=%d W=%d", B, H, W);
     const int ks = L.ks;
     if (compute_bf16()) return launch_conv_bf16(L, x, y, B, H, W, pool, relu, up_src, up_c, s, residual);
+    if (ks == 3 && !up_src && conv3x3_winograd() == 2 && conv_wino4_fits(L, H, W, pool))
+        return launch_conv_wino4(L, x, y, B, H, W, pool, relu, residual, s);
     if (ks == 3 && L.w_wino.ptr && !up_src && conv3x3_winograd() && (int64_t)H * W * L.cin * 4 < (1ll << 31))
         return launch_conv_wino(L, x, y, B, H, W, pool, relu, residual, s);
     if (ks != 3 && L.w_gemm.ptr && !up_src && !residual && pool == 0 && flat_gemm()) return launch_gemm_f32(L, x, y, B, H, W, relu, s);

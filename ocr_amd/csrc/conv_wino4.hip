@@ -1,0 +1,421 @@
+// 3x3 convolution (stride 1, zero padding 1) by the Winograd minimal-filtering algorithm F(4x4, 3x3) on the f32 matrix
+// cores, NHWC float32.
+//
+// Same layers as conv_wino.hip (the wide 3x3 convolutions of architectures/east_arch.py:114-151 and of the feature
+// extractors of architectures/crnn_arch.py:38-41,330-477), same folded batch-norm, bias, ReLU, fused 2x2 max-pool and
+// residual operand.  Every 4x4 block of outputs is computed from its 6x6 input patch d and the 3x3 filter g as
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A           (interpolation points 0, +-1, +-2, infinity)
+// i.e. 36 multiplications per input channel for 16 outputs instead of 144: the matrix cores execute 4x fewer flops
+// than the direct convolution performs (F(2x2,3x3): 2.25x).  The price is arithmetic: the transforms multiply by
+// constants up to 8 and 1/24, and the float32 result differs from the direct sum by up to ~1e-5 of the output scale
+// per layer (measured: 3.8e-6 on the detector's maps after its 16 such layers, against a tolerance of 1e-4).  The
+// filter transform is done once at load time in double.
+//
+// Tiling: a workgroup (8 waves, one per CU, two waves per SIMD) computes 16 rows x 32 columns of outputs = 4 x 8
+// blocks of 4x4, times 64 output channels.  The 36 Winograd components are 36 independent GEMMs (32 blocks x Cin) x
+// (Cin x 64); wave (gr, gc, ch) owns the 3x3 components (3 gr + 0..2, 3 gc + 0..2) for 32 blocks x channels
+// 32 ch .. 32 ch + 31: 9 accumulators of 32x32 = 144 registers.
+//   K: chunks of 8 input channels.  The raw tile with its halo (18 x 34 pixels) is staged in LDS, transformed into
+//   U[component][block][channel] in LDS by all threads (task = (block, channel pair, component row): a row of B^T d,
+//   then (.) B along it), and every lane loads its transformed-filter fragments straight from a lane-linear slab.
+//   U and the raw tile are double buffered, one barrier per chunk; a wave transforms chunk k + 1 and then multiplies
+//   chunk k, so while one wave of a SIMD is in its transform the other one has MFMAs to issue.
+//   Epilogue: each wave applies its share of the inverse transform (A^T restricted to its rows, A to its columns) and
+//   the four waves of a channel half add their partial outputs in turn into an LDS staging area, which the output
+//   pass (bias, residual, ReLU, optional max-pool) writes as 16-byte stores.
+//
+// Roofline: MFMA bound; the unit of work is the direct convolution's 2*9*Cin*Cout flop per output pixel, of which
+// 36/144 are executed.
+#include <type_traits>
+
+#include "common.h"
+
+namespace ocrhip {
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+constexpr int kCK = 8;                          // input channels per chunk
+constexpr int kRS = 12;                         // floats per raw pixel in LDS
+constexpr int kRawW = 34, kRawH = 18, kRawPx = kRawW * kRawH;
+constexpr int kRFloats = kRawPx * kRS;
+constexpr int kRBuf = kRFloats + 4;             // + a spare slot for the threads without a pixel
+constexpr int kUC = 32 * kCK;                   // floats per component of U: 32 blocks x 8 channels
+constexpr int kUFloats = 36 * kUC;
+constexpr int kLoopFloats = 2 * kUFloats + 2 * kRBuf;
+constexpr int kOS = 64 + 4;                     // floats per staged output pixel
+constexpr int kPartFloats = 128 * kOS;          // one wave group's share of a block row (4 x 32 pixels x 64 channels)
+constexpr int kStageFloats = 4 * kPartFloats;
+constexpr int kLdsBytes = 4 * (kLoopFloats > kStageFloats ? kLoopFloats : kStageFloats);
+constexpr int kWChunkFloats = 36 * 2 * 64 * 4;  // transformed filters of one chunk of one 64-channel block
+
+// B^T (6x6), by output row: the (at most four) input rows it combines and their coefficients
+__constant__ int c_bt_row[6][4] = {{0, 2, 4, 1}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 3, 5, 2}};
+__constant__ float c_bt_coef[6][4] = {{4.f, -5.f, 1.f, 0.f}, {-4.f, -4.f, 1.f, 1.f}, {4.f, -4.f, -1.f, 1.f},
+                                      {-2.f, -1.f, 2.f, 1.f}, {2.f, -1.f, -2.f, 1.f}, {4.f, -5.f, 1.f, 0.f}};
+struct Wino4Args {
+    const float* x;        // (B,H,W,cin)
+    const float* w;        // transformed filters, slab layout of prepare_conv_wino4
+    const float* bias;     // cout_pad
+    const float* res;      // optional residual (POOL == 0), shaped like y
+    float* y;
+    int B, H, W, cin, cout, relu;
+    int tiles_x, tiles_per_image, n_blocks_n;
+};
+
+// Share of the 3x3 components (3 GR + ii, 3 GC + jj) in the 4x4 outputs of a block: Y = At_r M At_c^T with At_r the
+// columns 3 GR .. 3 GR + 2 of A^T (4x6) = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] and At_c likewise for GC.
+// The coefficients are compile-time constants: zeros and ones cost nothing.
+template <int G>
+__device__ __forceinline__ void at_apply(float m0, float m1, float m2, float (&o)[4]) {
+    if (G == 0) {            // columns 0..2: [1 1 1; 0 1 -1; 0 1 1; 0 1 -1]
+        o[1] = m1 - m2;
+        o[2] = m1 + m2;
+        o[0] = m0 + o[2];
+        o[3] = o[1];
+    } else {                 // columns 3..5: [1 1 0; 2 -2 0; 4 4 0; 8 -8 1]
+        const float s = m0 + m1, d = m0 - m1;
+        o[0] = s;
+        o[1] = 2.0f * d;
+        o[2] = 4.0f * s;
+        o[3] = 8.0f * d + m2;
+    }
+}
+template <int GR, int GC>
+__device__ __forceinline__ void inverse_part(const float (&M)[3][3], float (&Y)[4][4]) {
+    float Wc[3][4];
+#pragma unroll
+    for (int ii = 0; ii < 3; ++ii) at_apply<GC>(M[ii][0], M[ii][1], M[ii][2], Wc[ii]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float col[4];
+        at_apply<GR>(Wc[0][c], Wc[1][c], Wc[2][c], col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[r][c] = col[r];
+    }
+}
+
+template <int POOL>
+__global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // U[2] then raw[2]: chunk j lives in buffer j & 1
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int ch = wave & 1, gc = (wave >> 1) & 1, gr = wave >> 2;
+
+    // every XCD (own L2) walks one contiguous range of the work index, the channel block varying fastest
+    const unsigned total = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned work = xcd * (total >> 3) + min(xcd, total & 7u) + slot;
+    const int nb = (int)(work % (unsigned)a.n_blocks_n);
+    const int tile_all = (int)(work / (unsigned)a.n_blocks_n);
+    const int b = tile_all / a.tiles_per_image;
+    const int tile = tile_all % a.tiles_per_image;
+    const int y0 = (tile / a.tiles_x) * 16, x0 = (tile % a.tiles_x) * 32;
+    const int nK = a.cin / kCK;
+
+    // bias now: a load still in flight in the epilogue would stall its guarded stores
+    const int c4 = tid & 15;
+    const int co0 = nb * 64 + c4 * 4;
+    const floatx4 bias4 = *reinterpret_cast<const floatx4*>(a.bias + co0);          // bias is padded to cout_pad
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[f][v] = 0.0f;
+
+    // Global loads go through buffer descriptors: a per-lane byte offset that never changes, the chunk as a scalar
+    // offset, and the range check, which returns zeros beyond the buffer: the zero padding around the image costs no
+    // instruction (lanes outside the image carry the offset 2^31).
+    const float* wslab = a.w + (int64_t)nb * nK * kWChunkFloats;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wslab, 0, nK * kWChunkFloats * 4, 0x00020000);
+    const int w_off = ((((3 * gr) * 6 + 3 * gc) * 2 + ch) * 64 + lane) * 16;
+    auto load_w = [&](int kc, int f) {          // fragment of component (3 gr + f / 3, 3 gc + f % 3) of chunk kc
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off, kc * (kWChunkFloats * 4) + ((f / 3) * 6 + f % 3) * 2048, 0));
+    };
+
+    // raw tile: 612 pixels x 2 channel quads over the threads (three or two per thread)
+    constexpr int NRAW = (kRawPx * 2 + 511) / 512;
+    const int64_t img_floats = (int64_t)a.H * a.W * a.cin;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + b * img_floats), 0, (int)(img_floats * 4), 0x00020000);
+    float4 ra[NRAW];
+    int raw_src[NRAW], raw_dst[NRAW];
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) {
+        const int f = tid + i * 512;
+        const int px = f >> 1, q = f & 1;
+        const int gy = y0 - 1 + px / kRawW, gx = x0 - 1 + px % kRawW;
+        const bool ok = f < kRawPx * 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        raw_src[i] = ok ? (((gy * a.W + gx) * a.cin + q * 4) * 4) : (int)0x80000000;
+        raw_dst[i] = (f < kRawPx * 2) ? (px * kRS + q * 4) : kRFloats;
+    }
+    auto load_raw = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i)
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, raw_src[i], kc * (kCK * 4), 0));
+    };
+    auto store_raw = [&](int rbase) {
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) *reinterpret_cast<float4*>(&lds[rbase + raw_dst[i]]) = ra[i];
+    };
+
+    // Data transform.  Wave task wt in [0, 12) = (block-row half, component row i); its lanes = (block row within the
+    // half, block column, channel pair).  A lane forms row i of B^T d for its block (6 columns, each a combination of
+    // 4 raw rows) and multiplies by B along the row: components (i, 0..5) of 2 channels.  Wave w runs task w, waves
+    // 0..3 also task 8 + w (every SIMD gets three tasks).
+    const int t_p = lane & 3, t_bx = (lane >> 2) & 7, t_bylo = lane >> 5;
+    auto transform_task = [&](int wt, int rbase, int ubase) {
+        const int i = wt % 6, by = (wt / 6) * 2 + t_bylo;
+        const int m = by * 8 + t_bx;
+        const float* src = &lds[rbase + ((by * 4) * kRawW + t_bx * 4) * kRS + t_p * 2];
+        const int r0 = c_bt_row[i][0] * (kRawW * kRS), r1 = c_bt_row[i][1] * (kRawW * kRS), r2 = c_bt_row[i][2] * (kRawW * kRS),
+                  r3 = c_bt_row[i][3] * (kRawW * kRS);
+        const float k0 = c_bt_coef[i][0], k1 = c_bt_coef[i][1], k2 = c_bt_coef[i][2], k3 = c_bt_coef[i][3];
+        floatx2 t[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const floatx2 d0 = *reinterpret_cast<const floatx2*>(src + r0 + c * kRS);
+            const floatx2 d1 = *reinterpret_cast<const floatx2*>(src + r1 + c * kRS);
+            const floatx2 d2 = *reinterpret_cast<const floatx2*>(src + r2 + c * kRS);
+            const floatx2 d3 = *reinterpret_cast<const floatx2*>(src + r3 + c * kRS);
+            t[c] = k0 * d0 + k1 * d1 + k2 * d2 + k3 * d3;
+        }
+        const floatx2 e1 = t[4] - 4.0f * t[2], e2 = t[3] - 4.0f * t[1], e3 = t[4] - t[2], e4 = 2.0f * (t[3] - t[1]);
+        floatx2 o[6];
+        o[0] = 4.0f * t[0] - 5.0f * t[2] + t[4];
+        o[1] = e1 + e2;
+        o[2] = e1 - e2;
+        o[3] = e3 + e4;
+        o[4] = e3 - e4;
+        o[5] = 4.0f * t[1] - 5.0f * t[3] + t[5];
+        // U[component][block m][8 channels]; the two 16-byte halves of a block swap places in blocks 8..15 and 24..31,
+        // which makes the MFMA operand reads (16 lanes = 16 blocks, one half) conflict free without padding
+        float* dst = &lds[ubase + (i * 6) * kUC + m * kCK + (((t_p >> 1) ^ ((m >> 3) & 1)) * 4) + (t_p & 1) * 2];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<floatx2*>(dst + j * kUC) = o[j];
+    };
+    auto transform = [&](int rbase, int ubase) {
+        transform_task(wave, rbase, ubase);
+        if (wave < 4) transform_task(8 + wave, rbase, ubase);
+    };
+
+    float4 bw[9], af[2][3];
+    const int u_src = ((3 * gr) * 6 + 3 * gc) * kUC + li * kCK + ((lh ^ ((li >> 3) & 1)) * 4);
+    auto af_read = [&](int ubase, int g) {       // component row 3 gr + g, columns 3 gc + 0..2
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) af[g & 1][jj] = *reinterpret_cast<const float4*>(&lds[ubase + u_src + (g * 6 + jj) * kUC]);
+    };
+
+    // prologue: chunk 0 transformed into U[0], raw tile 1 in raw[1], raw tile 2 on its way, filter fragments of chunk 0
+    constexpr int kR0 = 2 * kUFloats, kR1 = 2 * kUFloats + kRBuf;
+    load_raw(0);
+#pragma unroll
+    for (int f = 0; f < 9; ++f) bw[f] = load_w(0, f);
+    store_raw(kR0);
+    load_raw(min(1, nK - 1));
+    __syncthreads();
+    transform(kR0, 0);
+    store_raw(kR1);
+    load_raw(min(2, nK - 1));
+    __syncthreads();
+
+    // Chunk kc.  On entry: U[kc & 1] complete, the chunk's filter fragments in registers, raw tile kc + 1 in
+    // raw[(kc + 1) & 1], raw tile kc + 2 in flight.  Past the end of K the same loads and stores run on the last chunk
+    // again and their results are not used.
+    auto chunk = [&](int kc, auto parity) {
+        constexpr int P = decltype(parity)::value;
+        constexpr int ucur = P * kUFloats, unxt = (1 - P) * kUFloats;
+        constexpr int rnxt = kR0 + (1 - P) * kRBuf, rfill = kR0 + P * kRBuf;
+        const int kn = min(kc + 1, nK - 1);
+        af_read(ucur, 0);
+        transform(rnxt, unxt);
+        store_raw(rfill);
+        load_raw(min(kc + 3, nK - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            if (g < 2) af_read(ucur, g + 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    const float4 a4 = af[g & 1][jj], b4 = bw[g * 3 + jj];
+                    const float av = t == 0 ? a4.x : (t == 1 ? a4.y : (t == 2 ? a4.z : a4.w));
+                    const float bv = t == 0 ? b4.x : (t == 1 ? b4.y : (t == 2 ? b4.z : b4.w));
+                    acc[g * 3 + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g * 3 + jj], 0, 0, 0);
+                }
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) bw[g * 3 + jj] = load_w(kn, g * 3 + jj);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    for (int kc = 0; kc < nK; kc += 2) {          // nK is even
+        chunk(kc, std::integral_constant<int, 0>{});
+        chunk(kc + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- inverse transform and output, one block row (4 x 32 outputs) at a time.  Register v of a lane belongs to block
+    // m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5), i.e. block row v >> 2, and to output channel lane & 31 of the wave's 32.
+    // The wave's 3x3 components contribute
+    //     Y[r][c] += sum_ii sum_jj A^T[r][3 gr + ii] M[ii][jj] A^T[c][3 gc + jj]
+    // to the 4x4 outputs of a block: every wave writes its share of the block row to its own staging area, and the
+    // output pass adds the four areas (in a fixed order) with bias, residual, ReLU and max-pool: 16-byte stores.
+    const int part = gr * 2 + gc;
+    const int oc = ch * 32 + li;
+    const bool vec_ok = (a.cout & 3) == 0 && co0 + 3 < a.cout;
+    auto max4 = [](floatx4 p, floatx4 q) { return floatx4{fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), fmaxf(p.w, q.w)}; };
+    auto staged = [&](int row, int col) {
+        const float* q = &lds[(row * 32 + col) * kOS + c4 * 4];
+        return (*reinterpret_cast<const floatx4*>(q) + *reinterpret_cast<const floatx4*>(q + kPartFloats)) +
+               (*reinterpret_cast<const floatx4*>(q + 2 * kPartFloats) + *reinterpret_cast<const floatx4*>(q + 3 * kPartFloats));
+    };
+    const int Ho = (POOL == 1) ? a.H / 2 : a.H, Wo = (POOL == 1) ? a.W / 2 : a.W;
+    constexpr int kOutW = (POOL == 1) ? 16 : 32, kOutH = (POOL == 1) ? 2 : 4;       // output pixels of a block row
+    constexpr int kIters = kOutW * kOutH / 32;
+#pragma unroll
+    for (int by = 0; by < 4; ++by) {
+        if (by > 0) __syncthreads();             // the output pass of the previous block row has read the staging areas
+        float* O = &lds[part * kPartFloats + oc];
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) {
+            const int v = by * 4 + vv;
+            const int bx = vv + 4 * lh;
+            float M[3][3];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) M[f / 3][f % 3] = acc[f][v];
+            float Y[4][4];
+            switch (part) {
+                case 0: inverse_part<0, 0>(M, Y); break;
+                case 1: inverse_part<0, 1>(M, Y); break;
+                case 2: inverse_part<1, 0>(M, Y); break;
+                default: inverse_part<1, 1>(M, Y); break;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) O[(r * 32 + bx * 4 + c) * kOS] = Y[r][c];
+        }
+        __syncthreads();
+        floatx4 vals[kIters];
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int px = (tid >> 4) + it * 32;
+            const int py = px / kOutW, pxx = px % kOutW;
+            if (POOL == 0) vals[it] = staged(py, pxx);
+            else vals[it] = max4(max4(staged(2 * py, 2 * pxx), staged(2 * py, 2 * pxx + 1)), max4(staged(2 * py + 1, 2 * pxx), staged(2 * py + 1, 2 * pxx + 1)));
+        }
+        const int oy0 = ((POOL == 1) ? (y0 >> 1) : y0) + by * kOutH, ox0 = (POOL == 1) ? (x0 >> 1) : x0;
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int px = (tid >> 4) + it * 32;
+            const int yy = oy0 + px / kOutW, xx = ox0 + px % kOutW;
+            if (yy >= Ho || xx >= Wo) continue;
+            floatx4 val = vals[it] + bias4;
+            const int64_t idx = (((int64_t)b * Ho + yy) * Wo + xx) * a.cout + co0;
+            if (vec_ok) {
+                if (POOL == 0 && a.res) val += *reinterpret_cast<const floatx4*>(a.res + idx);
+                if (a.relu) {
+                    val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
+                }
+                *reinterpret_cast<floatx4*>(a.y + idx) = val;
+            } else {
+                const float e[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (co0 + k < a.cout) {
+                        float o1 = e[k];
+                        if (POOL == 0 && a.res) o1 += a.res[idx + k];
+                        if (a.relu) o1 = fmaxf(o1, 0.0f);
+                        a.y[idx + k] = o1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Transformed-filter slab: [n block (64 channels)][k chunk (8)][component f = 6 i + j][channel half c][h][j32][t]
+// float32 with output channel = nblock * 64 + c * 32 + j32 and input channel = kchunk * 8 + 4 h + t: lane (h * 32 + j32)
+// of a wave that owns channel half c reads 16 consecutive bytes per component.
+int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
+    OCR_REQUIRE(cin % (2 * kCK) == 0 && cout > 0, "conv_wino4: cin=%d must be a multiple of %d", cin, 2 * kCK);
+    const int nN = (cout + 63) / 64, nK = cin / kCK;
+    std::vector<float> w((size_t)nN * nK * kWChunkFloats, 0.0f);
+    static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c) {
+            const float* g = w_oihw + ((size_t)o * cin + c) * 9;
+            double tmp[6][3], V[6][6];
+            for (int i = 0; i < 6; ++i)
+                for (int k = 0; k < 3; ++k) tmp[i][k] = G[i][0] * g[0 * 3 + k] + G[i][1] * g[1 * 3 + k] + G[i][2] * g[2 * 3 + k];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) V[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+            const int nbk = o / 64, chalf = (o % 64) / 32, j32 = o % 32;
+            const int kc = c / kCK, hh = (c % kCK) / 4, t = c % 4;
+            for (int f = 0; f < 36; ++f) {
+                const size_t dst = ((((((size_t)(nbk * nK + kc) * 36 + f) * 2 + chalf) * 2 + hh) * 32 + j32) * 4) + t;
+                w[dst] = (float)V[f / 6][f % 6];
+            }
+        }
+    OCR_TRY(L.w_wino4.reserve(w.size() * sizeof(float)));
+    OCR_HIP_CHECK(hipMemcpy(L.w_wino4.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    return OCRHIP_OK;
+}
+
+// Whether the F(4x4,3x3) kernel serves this launch (16 x 32 tiles reasonably full, pooling none or 2x2).
+bool conv_wino4_fits(const ConvLayer& L, int H, int W, int pool) {
+    if (!L.w_wino4.ptr || pool == 2 || (int64_t)H * W * L.cin * 4 >= (1ll << 31)) return false;
+    const double fill = (double)H * W / ((double)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32));
+    return fill >= 0.7;
+}
+
+int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
+                      const float* residual, hipStream_t s) {
+    OCR_REQUIRE(L.ks == 3 && L.w_wino4.ptr, "conv_wino4: layer has no transformed filters");
+    OCR_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "conv_wino4: bad arguments B=%d H=%d W=%d", B, H, W);
+    OCR_REQUIRE(L.cout_pad % 64 == 0 && L.cin % (2 * kCK) == 0, "conv_wino4: layer shape %d -> %d not supported", L.cin, L.cout);
+    OCR_REQUIRE((int64_t)H * W * L.cin * 4 < (1ll << 31), "conv_wino4: image of %dx%dx%d floats exceeds the 2 GB of a buffer descriptor", H, W, L.cin);
+    OCR_REQUIRE(pool == 0 || pool == 1, "conv_wino4: bad pool mode %d", pool);
+    if (pool) OCR_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_wino4: pooled layer needs even size, got %dx%d", H, W);
+    OCR_REQUIRE(!residual || pool == 0, "conv_wino4: a residual goes with an unpooled layer");
+    Wino4Args a;
+    a.x = x; a.w = L.w_wino4.as<float>(); a.bias = L.bias.as<float>(); a.res = residual; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.cin = L.cin; a.cout = L.cout; a.relu = relu ? 1 : 0;
+    a.tiles_x = (W + 31) / 32;
+    a.tiles_per_image = a.tiles_x * ((H + 15) / 16);
+    a.n_blocks_n = L.cout_pad / 64;
+    const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
+    OCR_REQUIRE(wgs < (1ll << 31), "conv_wino4: too many workgroups");
+    char pname[64];
+    std::snprintf(pname, sizeof(pname), "conv_wino4_f32<p%d,c%d-%d,h%d>", pool, L.cin, L.cout, H);
+    const double out_px = (double)B * H * W;
+    const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : 1.0);
+    ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
+                   4.0 * (out_px * L.cin + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout), s);
+    static bool lds_opt_in_dev[64] = {};        // more than 64 KB of LDS per workgroup needs an opt-in per kernel and device
+    int dev = 0;
+    OCR_HIP_CHECK(hipGetDevice(&dev));
+    bool& lds_opt_in = lds_opt_in_dev[dev & 63];
+    if (!lds_opt_in) {
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        lds_opt_in = true;
+    }
+    if (pool == 0)
+        hipLaunchKernelGGL((conv_wino4_f32_kernel<0>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
+    else
+        hipLaunchKernelGGL((conv_wino4_f32_kernel<1>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
+    OCR_HIP_CHECK(hipGetLastError());
+    return OCRHIP_OK;
+}
+
+}  // namespace ocrhip

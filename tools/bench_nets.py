@@ -21,11 +21,15 @@ ap.add_argument('--wpad', type=int, default=192)
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--backbone', default='vgg', choices=['vgg', 'resnet'])
 ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+ap.add_argument('--opt', action='append', default=[], help='name=value passed to ocrhip_set_option')
 args = ap.parse_args()
 
 from ocr_amd._lib import BF16, F32  # noqa: E402
 DT = BF16 if args.dtype == 'bf16' else F32
 ctx = HipContext(0)
+for o in args.opt:
+    k, v = o.split('=')
+    ctx.set_option(k, int(v))
 ctx.east_load_weights(random_east_params(1))
 ctx.crnn_load_weights(random_crnn_params(97, seed=2, backbone=args.backbone))
 img = torch.randint(0, 256, (args.batch, args.size, args.size, 3), dtype=torch.uint8, device='cuda')
