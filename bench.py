@@ -129,12 +129,13 @@ def main():
 
     if rank == 0:
         pages = world * args.steps * B
-        mfma = [s for s in stats if s['flops'] > 0 and s['name'].startswith(('conv_mfma', 'conv_wino', 'conv_bf16'))]
+        mfma = [s for s in stats if s['flops'] > 0 and s['name'].startswith(('conv_mfma', 'conv_wino', 'conv_bf16', 'gemm_f32'))]
         dom = max(mfma, key=lambda s: s['total_ms'])
         achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
         # the Winograd kernel is credited with the flop count of the convolution it computes (2*9*Cin*Cout per output
         # pixel) but its matrix cores execute 16/36 of that: `executed` is what the MFMA peak actually bounds
-        executed = achieved * (16.0 / 36.0 if dom['name'].startswith('conv_wino') else 1.0)
+        wino_frac = 0.25 if dom['name'].startswith('conv_wino4') else (16.0 / 36.0 if dom['name'].startswith('conv_wino') else 1.0)
+        executed = achieved * wino_frac
         peak = BF16_MFMA_PEAK_TFLOPS if dom['name'].startswith('conv_bf16') else F32_MFMA_PEAK_TFLOPS
         gpu_ms = sum(s['total_ms'] for s in stats)
         conv_ms = sum(s['total_ms'] for s in mfma)
@@ -153,8 +154,10 @@ def main():
                          'avg_ms': dom['total_ms'] / dom['launches'], 'achieved': achieved,
                          'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'executed_tflops': executed, 'executed_frac': executed / peak,
-                         'algorithm': ('Winograd F(2x2,3x3): `achieved` counts the direct convolution\'s flops, the matrix '
-                                       'cores execute 16/36 of them (`executed`)') if dom['name'].startswith('conv_wino')
+                         'algorithm': ('Winograd F(4x4,3x3): `achieved` counts the direct convolution\'s flops, the matrix '
+                                       'cores execute 36/144 of them (`executed`)') if dom['name'].startswith('conv_wino4')
+                         else ('Winograd F(2x2,3x3): `achieved` counts the direct convolution\'s flops, the matrix '
+                               'cores execute 16/36 of them (`executed`)') if dom['name'].startswith('conv_wino')
                          else 'direct implicit GEMM',
                          'traffic': pmc_traffic(dom['name']),
                          'algorithmic_bytes': dom['bytes'] / dom['launches'],

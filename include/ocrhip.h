@@ -62,9 +62,11 @@ int ocrhip_create(int device, ocrhip_handle* out);
 int ocrhip_destroy(ocrhip_handle h);
 
 /* Options of a handle (no counterpart in the reference; Keras picks its convolution algorithm itself).
- *   "conv3x3_winograd": 1 (default) computes the 3x3 convolutions with >= 64 output channels by Winograd
- *   F(2x2,3x3) in float32 (2.25x fewer multiplications, results within float32 rounding of the direct sum);
- *   0 computes them as a direct implicit GEMM (a float32 fma chain over the taps and channels).
+ *   "conv3x3_winograd": how the 3x3 convolutions with >= 64 output channels are computed, always in float32.
+ *   2 (default): Winograd F(4x4,3x3) (4x fewer multiplications; results within ~1e-5 of the output scale of the direct
+ *   sum per layer) for the launches whose feature map fills that kernel's 16x32 tiles, F(2x2,3x3) for the others;
+ *   1: F(2x2,3x3) everywhere (2.25x fewer multiplications, results within float32 rounding of the direct sum);
+ *   0: a direct implicit GEMM (a float32 fma chain over the taps and channels).
  *   "lstm_persistent": 1 (default) runs the recurrence of a BiLSTM layer as one launch of persistent workgroups
  *   (W_hh resident in LDS, h_t handed over through L2); 0 launches one kernel per time step.  Same arithmetic.
  *   "flat_gemm": 1 (default) runs the Dense layers, the LSTM input projections and the 2x2 convolutions as a flat

@@ -34,7 +34,7 @@ struct Bf16Scope {
 static thread_local int g_lstm_persistent = 1;
 int lstm_persistent() { return g_lstm_persistent; }
 void set_lstm_persistent(int on) { g_lstm_persistent = on; }
-static thread_local int g_conv3x3_winograd = 1;
+static thread_local int g_conv3x3_winograd = 2;
 int conv3x3_winograd() { return g_conv3x3_winograd; }
 void set_conv3x3_winograd(int on) { g_conv3x3_winograd = on; }
 static thread_local int g_flat_gemm = 1;

@@ -148,7 +148,7 @@ struct ocrhip_ctx {
     ocrhip::DevBuf decode_stage;   // staging of the decode kernel
     ocrhip::DevBuf lanms_ws;       // scratch of the LANMS kernel
     int lstm_persistent = 1;       // recurrence of a BiLSTM layer in one persistent launch (1) or one launch per step (0)
-    int conv3x3_winograd = 1;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
+    int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     int flat_gemm = 1;             // 1x1 / 2x2 layers on the 256 x 128 flat GEMM (1) or on the implicit-GEMM convolution kernel (0)
     ocrhip::Profiler prof;
 };

@@ -20,9 +20,9 @@
 //   then (.) B along it), and every lane loads its transformed-filter fragments straight from a lane-linear slab.
 //   U and the raw tile are double buffered, one barrier per chunk; a wave transforms chunk k + 1 and then multiplies
 //   chunk k, so while one wave of a SIMD is in its transform the other one has MFMAs to issue.
-//   Epilogue: each wave applies its share of the inverse transform (A^T restricted to its rows, A to its columns) and
-//   the four waves of a channel half add their partial outputs in turn into an LDS staging area, which the output
-//   pass (bias, residual, ReLU, optional max-pool) writes as 16-byte stores.
+//   Epilogue, one block row (4 x 32 outputs) at a time: each wave applies its share of the inverse transform (A^T
+//   restricted to its rows, A to its columns) and leaves its partial outputs in its own LDS staging area; the output
+//   pass adds the four areas, then bias, residual, ReLU and the optional max-pool, and writes 16-byte stores.
 //
 // Roofline: MFMA bound; the unit of work is the direct convolution's 2*9*Cin*Cout flop per output pixel, of which
 // 36/144 are executed.
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         return (*reinterpret_cast<const floatx4*>(q) + *reinterpret_cast<const floatx4*>(q + kPartFloats)) +
                (*reinterpret_cast<const floatx4*>(q + 2 * kPartFloats) + *reinterpret_cast<const floatx4*>(q + 3 * kPartFloats));
     };
-    const int Ho = (POOL == 1) ? a.H / 2 : a.H, Wo = (POOL == 1) ? a.W / 2 : a.W;
-    constexpr int kOutW = (POOL == 1) ? 16 : 32, kOutH = (POOL == 1) ? 2 : 4;       // output pixels of a block row
+    const int Ho = (POOL == 0) ? a.H : a.H / 2, Wo = (POOL == 1) ? a.W / 2 : a.W;
+    constexpr int kOutW = (POOL == 1) ? 16 : 32, kOutH = (POOL == 0) ? 4 : 2;       // output pixels of a block row
     constexpr int kIters = kOutW * kOutH / 32;
 #pragma unroll
     for (int by = 0; by < 4; ++by) {
@@ -308,9 +308,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
             const int px = (tid >> 4) + it * 32;
             const int py = px / kOutW, pxx = px % kOutW;
             if (POOL == 0) vals[it] = staged(py, pxx);
-            else vals[it] = max4(max4(staged(2 * py, 2 * pxx), staged(2 * py, 2 * pxx + 1)), max4(staged(2 * py + 1, 2 * pxx), staged(2 * py + 1, 2 * pxx + 1)));
+            else if (POOL == 1) vals[it] = max4(max4(staged(2 * py, 2 * pxx), staged(2 * py, 2 * pxx + 1)), max4(staged(2 * py + 1, 2 * pxx), staged(2 * py + 1, 2 * pxx + 1)));
+            else vals[it] = max4(staged(2 * py, pxx), staged(2 * py + 1, pxx));
         }
-        const int oy0 = ((POOL == 1) ? (y0 >> 1) : y0) + by * kOutH, ox0 = (POOL == 1) ? (x0 >> 1) : x0;
+        const int oy0 = ((POOL == 0) ? y0 : (y0 >> 1)) + by * kOutH, ox0 = (POOL == 1) ? (x0 >> 1) : x0;
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             const int px = (tid >> 4) + it * 32;
@@ -371,9 +372,9 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
     return OCRHIP_OK;
 }
 
-// Whether the F(4x4,3x3) kernel serves this launch (16 x 32 tiles reasonably full, pooling none or 2x2).
+// Whether the F(4x4,3x3) kernel serves this launch (16 x 32 tiles reasonably full).
 bool conv_wino4_fits(const ConvLayer& L, int H, int W, int pool) {
-    if (!L.w_wino4.ptr || pool == 2 || (int64_t)H * W * L.cin * 4 >= (1ll << 31)) return false;
+    if (!L.w_wino4.ptr || (int64_t)H * W * L.cin * 4 >= (1ll << 31)) return false;
     const double fill = (double)H * W / ((double)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32));
     return fill >= 0.7;
 }
@@ -384,8 +385,8 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     OCR_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "conv_wino4: bad arguments B=%d H=%d W=%d", B, H, W);
     OCR_REQUIRE(L.cout_pad % 64 == 0 && L.cin % (2 * kCK) == 0, "conv_wino4: layer shape %d -> %d not supported", L.cin, L.cout);
     OCR_REQUIRE((int64_t)H * W * L.cin * 4 < (1ll << 31), "conv_wino4: image of %dx%dx%d floats exceeds the 2 GB of a buffer descriptor", H, W, L.cin);
-    OCR_REQUIRE(pool == 0 || pool == 1, "conv_wino4: bad pool mode %d", pool);
-    if (pool) OCR_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_wino4: pooled layer needs even size, got %dx%d", H, W);
+    OCR_REQUIRE(pool >= 0 && pool <= 2, "conv_wino4: bad pool mode %d", pool);
+    if (pool) OCR_REQUIRE(H % 2 == 0 && (pool == 2 || W % 2 == 0), "conv_wino4: pooled layer needs even size, got %dx%d", H, W);
     OCR_REQUIRE(!residual || pool == 0, "conv_wino4: a residual goes with an unpooled layer");
     Wino4Args a;
     a.x = x; a.w = L.w_wino4.as<float>(); a.bias = L.bias.as<float>(); a.res = residual; a.y = y;
@@ -396,9 +397,9 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
     OCR_REQUIRE(wgs < (1ll << 31), "conv_wino4: too many workgroups");
     char pname[64];
-    std::snprintf(pname, sizeof(pname), "conv_wino4_f32<p%d,c%d-%d,h%d>", pool, L.cin, L.cout, H);
+    std::snprintf(pname, sizeof(pname), "conv_wino4_f32<n64,pool%d,tile16x32>", pool);
     const double out_px = (double)B * H * W;
-    const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : 1.0);
+    const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : (pool == 2 ? 2.0 : 1.0));
     ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
                    4.0 * (out_px * L.cin + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout), s);
     static bool lds_opt_in_dev[64] = {};        // more than 64 KB of LDS per workgroup needs an opt-in per kernel and device
@@ -408,12 +409,15 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     if (!lds_opt_in) {
         OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         lds_opt_in = true;
     }
     if (pool == 0)
         hipLaunchKernelGGL((conv_wino4_f32_kernel<0>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
-    else
+    else if (pool == 1)
         hipLaunchKernelGGL((conv_wino4_f32_kernel<1>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
+    else
+        hipLaunchKernelGGL((conv_wino4_f32_kernel<2>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }

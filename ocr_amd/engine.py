@@ -91,7 +91,8 @@ class HipContext:
         self.east_loaded = True
 
     def set_option(self, name, value):
-        """'conv3x3_winograd': 1 (default) Winograd F(2x2,3x3) for the wide 3x3 convolutions, 0 direct implicit GEMM.
+        """'conv3x3_winograd': 2 (default) Winograd F(4x4,3x3) where the map fills its tiles and F(2x2,3x3) elsewhere,
+        1 F(2x2,3x3) for all wide 3x3 convolutions, 0 direct implicit GEMM.
         'lstm_persistent': 1 (default) one persistent launch per BiLSTM layer, 0 one launch per time step.
         'flat_gemm': 1 (default) Dense layers / LSTM input projections / 2x2 convolutions on the 256 x 128 flat GEMM,
         0 on the implicit-GEMM convolution kernel."""

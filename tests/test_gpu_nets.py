@@ -141,30 +141,36 @@ def test_crnn_resnet_backbone_matches_oracle(ctx, n, Wpad):
 
 
 def test_direct_3x3_path_matches_oracle_too(ctx):
-    """`conv3x3_winograd = 0`: the 3x3 layers as a direct implicit GEMM (the default is Winograd F(2x2,3x3));
-    both agree with the oracle to the stated tolerance and with each other."""
+    """`conv3x3_winograd`: 2 (default) Winograd F(4x4,3x3) where the maps fill its 16x32 tiles and F(2x2,3x3) elsewhere,
+    1 F(2x2,3x3) everywhere, 0 the 3x3 layers as a direct implicit GEMM.  All three agree with the oracle to the
+    stated tolerance (1e-4 relative) and with each other."""
     params = nets.init_east_params(seed=1)
     ctx.east_load_weights(params)
     rng = np.random.default_rng(77)
-    img = rng.integers(0, 256, (1, 96, 160, 3), dtype=np.uint8)
+    img = rng.integers(0, 256, (2, 128, 224, 3), dtype=np.uint8)       # 128x224 and 64x112 maps take the 4x4 kernel
     ref = nets.east_forward(params, np.stack([oimg.prepare_east_input(i) for i in img])).numpy()
-    wino = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
-    ctx.set_option('conv3x3_winograd', 0)
+    cp = nets.init_crnn_params(vocab_size=97, seed=2)
+    ctx.crnn_load_weights(cp)
+    x = rng.uniform(-1, 1, (3, 64, 144, 1)).astype(np.float32)
+    cref = nets.crnn_forward(cp, x).numpy()
+    maps = {}
     try:
-        direct = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
-        cp = nets.init_crnn_params(vocab_size=97, seed=2)
-        ctx.crnn_load_weights(cp)
-        x = rng.uniform(-1, 1, (3, 64, 144, 1)).astype(np.float32)
-        got = ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True)['logits'].cpu().numpy()
-        cref = nets.crnn_forward(cp, x).numpy()
-        _close(got, cref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(cref).max())))
+        for opt in (0, 1, 2):
+            ctx.set_option('conv3x3_winograd', opt)
+            maps[opt] = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
+            got = ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True)['logits'].cpu().numpy()
+            _close(got, cref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(cref).max())))
     finally:
-        ctx.set_option('conv3x3_winograd', 1)
-    _close(direct, ref, rtol=1e-4, atol=1e-5)
-    _close(wino, ref, rtol=1e-4, atol=1e-5)
-    _close(wino, direct, rtol=1e-4, atol=1e-5)
+        ctx.set_option('conv3x3_winograd', 2)
+    for opt in (0, 1, 2):
+        _close(maps[opt], ref, rtol=1e-4, atol=1e-5)
+    _close(maps[1], maps[0], rtol=1e-4, atol=1e-5)
+    _close(maps[2], maps[0], rtol=1e-4, atol=1e-5)
+    assert not np.array_equal(maps[2], maps[1])          # the 4x4 kernel did run
     with pytest.raises(ValueError):
         ctx.set_option('no_such_option', 1)
+    with pytest.raises(ValueError):
+        ctx.set_option('conv3x3_winograd', 3)
 
 
 def test_lstm_per_step_launches_match_the_persistent_layer(ctx):
