@@ -22,6 +22,12 @@ def stage_name(kernel):
         rows, cols = (256, 1) if ks == 1 else (4 * mt * (32 // tw), tw)
         return 'conv_mfma_f32<ks%d,n%d,pool%s,up%d,tile%dx%d>' % (ks, 32 * int(m.group(2)), m.group(3),
                                                                   m.group(4) == 'true', rows, cols)
+    m = re.search(r'conv_wino4_f32_kernel<(\d+)>', kernel)
+    if m:
+        return 'conv_wino4_f32<n64,pool%s,tile16x32>' % m.group(1)
+    m = re.search(r'lstm_layer_kernel', kernel)
+    if m:
+        return 'lstm_layer'
     m = re.search(r'conv_wino_f32_kernel<(\d+), (\d+)>', kernel)
     if m:
         return 'conv_wino_f32<n%d,pool%s,tile4x32>' % (32 * int(m.group(2)), m.group(1))
