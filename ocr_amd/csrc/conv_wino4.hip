@@ -52,10 +52,6 @@ constexpr int kStageFloats = 4 * kPartFloats;
 constexpr int kLdsBytes = 4 * (kLoopFloats > kStageFloats ? kLoopFloats : kStageFloats);
 constexpr int kWChunkFloats = 36 * 2 * 64 * 4;  // transformed filters of one chunk of one 64-channel block
 
-// B^T (6x6), by output row: the (at most four) input rows it combines and their coefficients
-__constant__ int c_bt_row[6][4] = {{0, 2, 4, 1}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 3, 5, 2}};
-__constant__ float c_bt_coef[6][4] = {{4.f, -5.f, 1.f, 0.f}, {-4.f, -4.f, 1.f, 1.f}, {4.f, -4.f, -1.f, 1.f},
-                                      {-2.f, -1.f, 2.f, 1.f}, {2.f, -1.f, -2.f, 1.f}, {4.f, -5.f, 1.f, 0.f}};
 struct Wino4Args {
     const float* x;        // (B,H,W,cin)
     const float* w;        // transformed filters, slab layout of prepare_conv_wino4
@@ -166,33 +162,44 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
 
     // Data transform.  Wave task wt in [0, 12) = (block-row half, component row i); its lanes = (block row within the
     // half, block column, channel pair).  A lane forms row i of B^T d for its block (6 columns, each a combination of
-    // 4 raw rows) and multiplies by B along the row: components (i, 0..5) of 2 channels.  Wave w runs task w, waves
-    // 0..3 also task 8 + w (every SIMD gets three tasks).
+    // 3 or 4 raw rows) and multiplies by B along the row: components (i, 0..5) of 2 channels.  Wave w runs task w, waves
+    // 0..3 also task 8 + w (every SIMD gets three tasks).  i is uniform in a wave: the code is specialised per row,
+    //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1].
     const int t_p = lane & 3, t_bx = (lane >> 2) & 7, t_bylo = lane >> 5;
     auto transform_task = [&](int wt, int rbase, int ubase) {
         const int i = wt % 6, by = (wt / 6) * 2 + t_bylo;
         const int m = by * 8 + t_bx;
         const float* src = &lds[rbase + ((by * 4) * kRawW + t_bx * 4) * kRS + t_p * 2];
-        const int r0 = c_bt_row[i][0] * (kRawW * kRS), r1 = c_bt_row[i][1] * (kRawW * kRS), r2 = c_bt_row[i][2] * (kRawW * kRS),
-                  r3 = c_bt_row[i][3] * (kRawW * kRS);
-        const float k0 = c_bt_coef[i][0], k1 = c_bt_coef[i][1], k2 = c_bt_coef[i][2], k3 = c_bt_coef[i][3];
+        constexpr int RW = kRawW * kRS;
+        auto rd = [&](int r, int c) { return *reinterpret_cast<const floatx2*>(src + r * RW + c * kRS); };
         floatx2 t[6];
+        if (i == 0 || i == 5) {                    // 4 d_a - 5 d_b + d_c with rows (0, 2, 4) or (1, 3, 5)
+            const int ra_ = i == 0 ? 0 : RW;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const floatx2 d0 = *reinterpret_cast<const floatx2*>(src + r0 + c * kRS);
-            const floatx2 d1 = *reinterpret_cast<const floatx2*>(src + r1 + c * kRS);
-            const floatx2 d2 = *reinterpret_cast<const floatx2*>(src + r2 + c * kRS);
-            const floatx2 d3 = *reinterpret_cast<const floatx2*>(src + r3 + c * kRS);
-            t[c] = k0 * d0 + k1 * d1 + k2 * d2 + k3 * d3;
+            for (int c = 0; c < 6; ++c) {
+                const floatx2 da = *reinterpret_cast<const floatx2*>(src + ra_ + c * kRS);
+                const floatx2 db = *reinterpret_cast<const floatx2*>(src + ra_ + 2 * RW + c * kRS);
+                const floatx2 dc = *reinterpret_cast<const floatx2*>(src + ra_ + 4 * RW + c * kRS);
+                t[c] = 4.0f * da + (dc - 5.0f * db);
+            }
+        } else {                                   // (d4 - q d2) + s p (d3 - q d1): q = 4, p = 1 (i = 1, 2); q = 1, p = 2 (i = 3, 4)
+            const float q = i <= 2 ? 4.0f : 1.0f;
+            const float sp = (i <= 2 ? 1.0f : 2.0f) * ((i & 1) ? 1.0f : -1.0f);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const floatx2 e1 = rd(4, c) - q * rd(2, c);
+                const floatx2 e2 = rd(3, c) - q * rd(1, c);
+                t[c] = e1 + sp * e2;
+            }
         }
-        const floatx2 e1 = t[4] - 4.0f * t[2], e2 = t[3] - 4.0f * t[1], e3 = t[4] - t[2], e4 = 2.0f * (t[3] - t[1]);
+        const floatx2 e1 = t[4] - 4.0f * t[2], e2 = t[3] - 4.0f * t[1], e3 = t[4] - t[2], e4 = t[3] - t[1];
         floatx2 o[6];
-        o[0] = 4.0f * t[0] - 5.0f * t[2] + t[4];
+        o[0] = 4.0f * t[0] + (t[4] - 5.0f * t[2]);
         o[1] = e1 + e2;
         o[2] = e1 - e2;
-        o[3] = e3 + e4;
-        o[4] = e3 - e4;
-        o[5] = 4.0f * t[1] - 5.0f * t[3] + t[5];
+        o[3] = e3 + 2.0f * e4;
+        o[4] = e3 - 2.0f * e4;
+        o[5] = 4.0f * t[1] + (t[5] - 5.0f * t[3]);
         // U[component][block m][8 channels]; the two 16-byte halves of a block swap places in blocks 8..15 and 24..31,
         // which makes the MFMA operand reads (16 lanes = 16 blocks, one half) conflict free without padding
         float* dst = &lds[ubase + (i * 6) * kUC + m * kCK + (((t_p >> 1) ^ ((m >> 3) & 1)) * 4) + (t_p & 1) * 2];
@@ -204,47 +211,53 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         if (wave < 4) transform_task(8 + wave, rbase, ubase);
     };
 
-    float4 bw[9], af[2][3];
+    float4 bw[9], af[3];
     const int u_src = ((3 * gr) * 6 + 3 * gc) * kUC + li * kCK + ((lh ^ ((li >> 3) & 1)) * 4);
     auto af_read = [&](int ubase, int g) {       // component row 3 gr + g, columns 3 gc + 0..2
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj) af[g & 1][jj] = *reinterpret_cast<const float4*>(&lds[ubase + u_src + (g * 6 + jj) * kUC]);
+        for (int jj = 0; jj < 3; ++jj) af[jj] = *reinterpret_cast<const float4*>(&lds[ubase + u_src + (g * 6 + jj) * kUC]);
     };
 
     // prologue: chunk 0 transformed into U[0], raw tile 1 in raw[1], raw tile 2 on its way, filter fragments of chunk 0
     constexpr int kR0 = 2 * kUFloats, kR1 = 2 * kUFloats + kRBuf;
-    load_raw(0);
+    {
+        float4 rb[NRAW];                         // raw tiles 0 and 1 requested together: one memory round trip
+        load_raw(0);
 #pragma unroll
-    for (int f = 0; f < 9; ++f) bw[f] = load_w(0, f);
-    store_raw(kR0);
-    load_raw(min(1, nK - 1));
+        for (int i = 0; i < NRAW; ++i)
+            rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, raw_src[i], kCK * 4, 0));
+#pragma unroll
+        for (int f = 0; f < 9; ++f) bw[f] = load_w(0, f);
+        store_raw(kR0);
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) *reinterpret_cast<float4*>(&lds[kR1 + raw_dst[i]]) = rb[i];
+    }
+    load_raw(min(2, nK - 1));
     __syncthreads();
     transform(kR0, 0);
-    store_raw(kR1);
-    load_raw(min(2, nK - 1));
     __syncthreads();
 
     // Chunk kc.  On entry: U[kc & 1] complete, the chunk's filter fragments in registers, raw tile kc + 1 in
-    // raw[(kc + 1) & 1], raw tile kc + 2 in flight.  Past the end of K the same loads and stores run on the last chunk
-    // again and their results are not used.
+    // raw[(kc + 1) & 1], raw tile kc + 2 in flight (past the end of K: the last chunk again, unused).
     auto chunk = [&](int kc, auto parity) {
         constexpr int P = decltype(parity)::value;
         constexpr int ucur = P * kUFloats, unxt = (1 - P) * kUFloats;
         constexpr int rnxt = kR0 + (1 - P) * kRBuf, rfill = kR0 + P * kRBuf;
         const int kn = min(kc + 1, nK - 1);
-        af_read(ucur, 0);
-        transform(rnxt, unxt);
-        store_raw(rfill);
-        load_raw(min(kc + 3, nK - 1));
+        if (kc + 1 < nK) {                          // uniform
+            transform(rnxt, unxt);
+            store_raw(rfill);
+            load_raw(min(kc + 3, nK - 1));
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-            if (g < 2) af_read(ucur, g + 1);
+            af_read(ucur, g);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) {
-                    const float4 a4 = af[g & 1][jj], b4 = bw[g * 3 + jj];
+                    const float4 a4 = af[jj], b4 = bw[g * 3 + jj];
                     const float av = t == 0 ? a4.x : (t == 1 ? a4.y : (t == 2 ? a4.z : a4.w));
                     const float bv = t == 0 ? b4.x : (t == 1 ? b4.y : (t == 2 ? b4.z : b4.w));
                     acc[g * 3 + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g * 3 + jj], 0, 0, 0);

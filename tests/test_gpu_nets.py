@@ -140,14 +140,17 @@ def test_crnn_resnet_backbone_matches_oracle(ctx, n, Wpad):
         ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=V, seed=2))      # leave the VGG recogniser loaded
 
 
-def test_direct_3x3_path_matches_oracle_too(ctx):
+@pytest.mark.parametrize('shape', [(2, 128, 224, 3), (1, 96, 160, 3)])
+def test_direct_3x3_path_matches_oracle_too(ctx, shape):
     """`conv3x3_winograd`: 2 (default) Winograd F(4x4,3x3) where the maps fill its 16x32 tiles and F(2x2,3x3) elsewhere,
     1 F(2x2,3x3) everywhere, 0 the 3x3 layers as a direct implicit GEMM.  All three agree with the oracle to the
     stated tolerance (1e-4 relative) and with each other."""
     params = nets.init_east_params(seed=1)
     ctx.east_load_weights(params)
     rng = np.random.default_rng(77)
-    img = rng.integers(0, 256, (2, 128, 224, 3), dtype=np.uint8)       # 128x224 and 64x112 maps take the 4x4 kernel
+    # (128, 224): 128x224 and 64x112 maps take the 4x4 kernel, the second with a half-empty last tile column;
+    # (96, 160): 96x160 and 48x80 maps, the second with partial tiles in both directions
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
     ref = nets.east_forward(params, np.stack([oimg.prepare_east_input(i) for i in img])).numpy()
     cp = nets.init_crnn_params(vocab_size=97, seed=2)
     ctx.crnn_load_weights(cp)
