@@ -40,7 +40,7 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 constexpr int kCK = 8;                          // input channels per chunk
 constexpr int kRS = 12;                         // floats per raw pixel in LDS
-constexpr int kRawW = 34, kRawH = 18, kRawPx = kRawW * kRawH;
+constexpr int kRawW = 34, kRawH = 20, kRawPx = kRawW * kRawH;      // 18 rows of one image, or 2 x 10 of a stacked pair
 constexpr int kRFloats = kRawPx * kRS;
 constexpr int kRBuf = kRFloats + 4;             // + a spare slot for the threads without a pixel
 constexpr int kUC = 32 * kCK;                   // floats per component of U: 32 blocks x 8 channels
@@ -60,6 +60,7 @@ struct Wino4Args {
     float* y;
     int B, H, W, cin, cout, relu;
     int tiles_x, tiles_per_image, n_blocks_n;
+    int pair;              // 1: images of 8 rows, two of them stacked in one tile (rows 0..7 and 8..15 of its outputs)
 };
 
 // Share of the 3x3 components (3 GR + ii, 3 GC + jj) in the 4x4 outputs of a block: Y = At_r M At_c^T with At_r the
@@ -111,8 +112,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     const int tile_all = (int)(work / (unsigned)a.n_blocks_n);
     const int b = tile_all / a.tiles_per_image;
     const int tile = tile_all % a.tiles_per_image;
-    const int y0 = (tile / a.tiles_x) * 16, x0 = (tile % a.tiles_x) * 32;
+    const int y0 = (tile / a.tiles_x) * 16, x0 = (tile % a.tiles_x) * 32;      // pair mode: b counts pairs, y0 = 0
     const int nK = a.cin / kCK;
+    const int pair = a.pair;
 
     // bias now: a load still in flight in the epilogue would stall its guarded stores
     const int c4 = tid & 15;
@@ -135,19 +137,24 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off, kc * (kWChunkFloats * 4) + ((f / 3) * 6 + f % 3) * 2048, 0));
     };
 
-    // raw tile: 612 pixels x 2 channel quads over the threads (three or two per thread)
+    // raw tile: 18 x 34 pixels (rows y0 - 1 .. y0 + 16) x 2 channel quads over the threads.  Pair mode: 20 rows = for each
+    // of the two images its 8 rows between two rows of zeros, so that no block reads its neighbour image as padding.
     constexpr int NRAW = (kRawPx * 2 + 511) / 512;
     const int64_t img_floats = (int64_t)a.H * a.W * a.cin;
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + b * img_floats), 0, (int)(img_floats * 4), 0x00020000);
+    const int n_img = pair ? min(2, a.B - 2 * b) : 1;          // a missing second image reads as zeros (range check)
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)b * (pair ? 2 : 1) * img_floats), 0,
+                                                                            (int)(n_img * img_floats * 4), 0x00020000);
     float4 ra[NRAW];
     int raw_src[NRAW], raw_dst[NRAW];
 #pragma unroll
     for (int i = 0; i < NRAW; ++i) {
         const int f = tid + i * 512;
         const int px = f >> 1, q = f & 1;
-        const int gy = y0 - 1 + px / kRawW, gx = x0 - 1 + px % kRawW;
-        const bool ok = f < kRawPx * 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        raw_src[i] = ok ? (((gy * a.W + gx) * a.cin + q * 4) * 4) : (int)0x80000000;
+        const int rr = px / kRawW, gx = x0 - 1 + px % kRawW;
+        const int img = (pair && rr >= 10) ? 1 : 0;
+        const int gy = pair ? rr - 10 * img - 1 : y0 - 1 + rr;
+        const bool ok = f < kRawPx * 2 && (pair || rr < 18) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        raw_src[i] = ok ? ((((img * a.H + gy) * a.W + gx) * a.cin + q * 4) * 4) : (int)0x80000000;
         raw_dst[i] = (f < kRawPx * 2) ? (px * kRS + q * 4) : kRFloats;
     }
     auto load_raw = [&](int kc) {
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     auto transform_task = [&](int wt, int rbase, int ubase) {
         const int i = wt % 6, by = (wt / 6) * 2 + t_bylo;
         const int m = by * 8 + t_bx;
-        const float* src = &lds[rbase + ((by * 4) * kRawW + t_bx * 4) * kRS + t_p * 2];
+        const float* src = &lds[rbase + ((by * 4 + (pair ? 2 * (by >> 1) : 0)) * kRawW + t_bx * 4) * kRS + t_p * 2];
         constexpr int RW = kRawW * kRS;
         auto rd = [&](int r, int c) { return *reinterpret_cast<const floatx2*>(src + r * RW + c * kRS); };
         floatx2 t[6];
@@ -324,14 +331,16 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
             else if (POOL == 1) vals[it] = max4(max4(staged(2 * py, 2 * pxx), staged(2 * py, 2 * pxx + 1)), max4(staged(2 * py + 1, 2 * pxx), staged(2 * py + 1, 2 * pxx + 1)));
             else vals[it] = max4(staged(2 * py, pxx), staged(2 * py + 1, pxx));
         }
-        const int oy0 = ((POOL == 0) ? y0 : (y0 >> 1)) + by * kOutH, ox0 = (POOL == 1) ? (x0 >> 1) : x0;
+        const int ob = pair ? 2 * b + (by >> 1) : b;                   // image of this block row
+        if (ob >= a.B) break;                                          // uniform: the pair's second image does not exist
+        const int oy0 = pair ? (by & 1) * kOutH : ((POOL == 0) ? y0 : (y0 >> 1)) + by * kOutH, ox0 = (POOL == 1) ? (x0 >> 1) : x0;
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             const int px = (tid >> 4) + it * 32;
             const int yy = oy0 + px / kOutW, xx = ox0 + px % kOutW;
             if (yy >= Ho || xx >= Wo) continue;
             floatx4 val = vals[it] + bias4;
-            const int64_t idx = (((int64_t)b * Ho + yy) * Wo + xx) * a.cout + co0;
+            const int64_t idx = (((int64_t)ob * Ho + yy) * Wo + xx) * a.cout + co0;
             if (vec_ok) {
                 if (POOL == 0 && a.res) val += *reinterpret_cast<const floatx4*>(a.res + idx);
                 if (a.relu) {
@@ -385,9 +394,10 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
     return OCRHIP_OK;
 }
 
-// Whether the F(4x4,3x3) kernel serves this launch (16 x 32 tiles reasonably full).
+// Whether the F(4x4,3x3) kernel serves this launch (16 x 32 tiles reasonably full; maps of 8 rows go in pairs).
 bool conv_wino4_fits(const ConvLayer& L, int H, int W, int pool) {
     if (!L.w_wino4.ptr || (int64_t)H * W * L.cin * 4 >= (1ll << 31)) return false;
+    if (H == 8) return (double)W / ((W + 31) / 32 * 32) >= 0.7;          // two images stacked per tile
     const double fill = (double)H * W / ((double)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32));
     return fill >= 0.7;
 }
@@ -405,9 +415,11 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     a.x = x; a.w = L.w_wino4.as<float>(); a.bias = L.bias.as<float>(); a.res = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.cin = L.cin; a.cout = L.cout; a.relu = relu ? 1 : 0;
     a.tiles_x = (W + 31) / 32;
-    a.tiles_per_image = a.tiles_x * ((H + 15) / 16);
+    a.pair = (H == 8) ? 1 : 0;
+    OCR_REQUIRE(!a.pair || (int64_t)2 * H * W * L.cin * 4 < (1ll << 31), "conv_wino4: image pair too large");
+    a.tiles_per_image = a.tiles_x * (a.pair ? 1 : (H + 15) / 16);
     a.n_blocks_n = L.cout_pad / 64;
-    const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
+    const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * (a.pair ? (B + 1) / 2 : B);
     OCR_REQUIRE(wgs < (1ll << 31), "conv_wino4: too many workgroups");
     char pname[64];
     std::snprintf(pname, sizeof(pname), "conv_wino4_f32<n64,pool%d,tile16x32>", pool);
