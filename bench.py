@@ -1,6 +1,6 @@
 """End-to-end OCR throughput on synthetic 1024x1024 dense-text pages (BASELINE.json config 4).
 
-    python bench.py --gpus 1 --steps 20 --warmup 2
+    python bench.py --gpus 1 --steps 40 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=16, help='pages per step and per GPU')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--words', type=int, default=220)
