@@ -2,10 +2,12 @@
 models/ocr/crnn.py:15-58), running on libocrhip.so.
 
 Same defaults as the reference (`combine=True`, `method='beam_search'`, 10 beams).  Beam search runs on
-the host from the GPU logits; `method='greedy'` decodes on the GPU.  `box_filters`, `dezoom_factor`,
-callbacks / savers / streaming are not built (NotImplementedError or ignored, never a silent change).
+the host from the GPU logits; `method='greedy'` decodes on the GPU.  Callbacks and the `map.json` prediction cache
+(`predict(save=True)`) work as in the reference (utils/saving.py); `box_filters`, `dezoom_factor`, the image saver,
+the displayer and camera streaming are not built (NotImplementedError, never a silent change).
 """
 import logging
+import os
 
 import numpy as np
 import torch
@@ -14,6 +16,7 @@ from .. import register_model
 from ..detection.east import get_image_data, load_image
 from ...runtimes import HIPRuntime
 from ...utils.image_sizes import plan_crops
+from ...utils.saving import FunctionCallback, JSONSaver, QueueCallback, apply_callbacks, load_json
 from ...utils.text import CharTokenizer, ENGLISH_G2_CHARACTERS
 
 logger = logging.getLogger(__name__)
@@ -143,6 +146,8 @@ class BaseOCR:
         (utils/combination.py) and every line is one recogniser input; the texts of a paragraph are
         joined with ' \n' like the reference does."""
         if predicted and not overwrite and isinstance(data, str) and data in predicted:
+            if callbacks:
+                apply_callbacks(callbacks, predicted[data], {}, save=False)
             return predicted[data]
         if box_filters or dezoom_factor != 1.:
             raise NotImplementedError('box_filters / dezoom_factor are not available in this build')
@@ -180,14 +185,55 @@ class BaseOCR:
             ocr_results.append(info)
             if box_callback is not None:
                 box_callback(info, image=image)
-        return {'filename': filename, 'boxes': data.get('boxes', None) if isinstance(data, dict) else None,
-                'ocr': ocr_results, 'image': image}
+        output = {'filename': filename, 'boxes': data.get('boxes', None) if isinstance(data, dict) else None,
+                  'ocr': ocr_results, 'image': image}
+        entry = None
+        if callbacks:
+            infos = {k: v for k, v in output.items() if 'image' not in k}
+            entry = apply_callbacks(callbacks, infos, output, save=True)
+        return output if return_output else (predicted or {}).get(entry, {})
 
-    def predict(self, inputs, **kwargs):
-        """base_ocr.py:371-375: a single image / filename / dict, or a list of them -> list of results."""
+    def get_inference_callbacks(self, *, save=True, directory=None, post_processing=None, **_):
+        """base_ocr.py:310-368 without the image saver and the displayer: with `save`, the results already in
+        `<directory>/map.json` and a saver that adds every new one (keyed by the input's filename)."""
+        predicted, callbacks = {}, []
+        if save:
+            if directory is None:
+                directory = os.path.join('pretrained_models', self.name, 'predictions')      # base_model.py:129
+            map_file = os.path.join(directory, 'map.json')
+            predicted = load_json(map_file, {})
+            callbacks.append(JSONSaver(data=predicted, filename=map_file, primary_key='filename'))
+        if post_processing is not None:
+            for fn in post_processing if isinstance(post_processing, list) else [post_processing]:
+                if callable(fn):
+                    callbacks.append(FunctionCallback(fn))
+                elif hasattr(fn, 'put'):
+                    callbacks.append(QueueCallback(fn))
+        return predicted, callbacks
+
+    def predict(self, inputs, *, predicted=None, callbacks=None, return_results=True, return_output=None,
+                save=False, directory=None, post_processing=None, **kwargs):
+        """base_ocr.py:371-375 over base_model.py:679-712: a single image / filename / dict, or a list of them -> list of
+        results.  `save=True` (the reference's default; off by default here so that nothing is written unasked) resumes
+        from and appends to `<directory>/map.json`: files already in it are not processed again, and the results
+        returned for saved inputs are the JSON entries, as in the reference."""
         if isinstance(inputs, (str, dict)) or (hasattr(inputs, 'shape') and len(inputs.shape) == 3):
             inputs = [inputs]
-        return [self.infer(inp, **kwargs) for inp in inputs]
+        join_callbacks = predicted is None
+        if predicted is None:
+            predicted, callbacks = self.get_inference_callbacks(save=save, directory=directory, post_processing=post_processing)
+        callbacks = callbacks or []
+        if return_output is None:
+            return_output = not any(isinstance(c, JSONSaver) for c in callbacks)
+        results = []
+        for inp in inputs:
+            out = self.infer(inp, predicted=predicted, callbacks=callbacks, return_output=return_output, **kwargs)
+            if return_results:
+                results.append(out)
+        if join_callbacks:
+            for c in callbacks:
+                c.join()
+        return results
 
 
 class CRNN(BaseOCR):
