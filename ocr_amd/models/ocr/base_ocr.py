@@ -3,8 +3,8 @@ models/ocr/crnn.py:15-58), running on libocrhip.so.
 
 Same defaults as the reference (`combine=True`, `method='beam_search'`, 10 beams).  Beam search runs on
 the host from the GPU logits; `method='greedy'` decodes on the GPU.  Callbacks and the `map.json` prediction cache
-(`predict(save=True)`) work as in the reference (utils/saving.py); `box_filters`, `dezoom_factor`, the image saver,
-the displayer and camera streaming are not built (NotImplementedError, never a silent change).
+(`predict(save=True)`) work as in the reference (utils/saving.py), so do `box_filters` (utils/filters.py);
+`dezoom_factor`, the image saver, the displayer and camera streaming are not built (NotImplementedError, never a silent change).
 """
 import logging
 import os
@@ -149,8 +149,8 @@ class BaseOCR:
             if callbacks:
                 apply_callbacks(callbacks, predicted[data], {}, save=False)
             return predicted[data]
-        if box_filters or dezoom_factor != 1.:
-            raise NotImplementedError('box_filters / dezoom_factor are not available in this build')
+        if dezoom_factor != 1.:
+            raise NotImplementedError('dezoom_factor is not available in this build')
         filename, image = get_image_data(data)
         if not isinstance(data, dict) or 'boxes' not in data:
             if isinstance(detector, str):
@@ -167,6 +167,9 @@ class BaseOCR:
             rows = [np.asarray(r, dtype=np.float32).reshape(-1, 4) for r in rows]
         else:
             rows = [boxes[i:i + 1] for i in range(len(boxes))]
+        if box_filters:                                     # base_ocr.py:164-165
+            from ...utils.filters import filter_boxes
+            boxes, _, rows = filter_boxes(box_filters, boxes, list(range(len(boxes))), rows)
         flat_rows = np.concatenate(rows).reshape(-1, 4) if rows else np.zeros((0, 4), np.float32)
         owner = np.concatenate([np.full(len(r), i) for i, r in enumerate(rows)]) if rows else np.zeros((0,), int)
         index, texts, scores = self.recognise_rows(np.asarray(image), flat_rows, method=method, num_beams=num_beams)
