@@ -114,6 +114,13 @@ __global__ __launch_bounds__(256) void conv_first_rows_kernel(const void* __rest
     constexpr int CPW = COUT / 4;
     constexpr int LDS_STRIDE = COUT + 4;
     __shared__ float tile[2][64 * LDS_STRIDE];
+    // uint8 input: the 256 possible normalised values, computed once per workgroup with the reference's float32
+    // operations (a division is ten instructions; converting a pixel's inputs in place costs a quarter of its FMAs)
+    __shared__ float lut[U8 ? 256 : 1];
+    if (U8) {
+        lut[threadIdx.x] = (((float)threadIdx.x / 255.0f) - 0.5f) / 0.5f;
+        __syncthreads();
+    }
 
     const int lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -133,8 +140,7 @@ __global__ __launch_bounds__(256) void conv_first_rows_kernel(const void* __rest
                 if (ok) {
                     const int64_t idx = (((int64_t)b * H + yy) * W + xx) * CIN + c;
                     if (U8) {
-                        const float u = (float)reinterpret_cast<const uint8_t*>(xin)[idx];
-                        v = ((u / 255.0f) - 0.5f) / 0.5f;
+                        v = lut[reinterpret_cast<const uint8_t*>(xin)[idx]];
                     } else {
                         v = reinterpret_cast<const float*>(xin)[idx];
                     }
