@@ -302,24 +302,31 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     for (int by = 0; by < 4; ++by) {
         if (by > 0) __syncthreads();             // the output pass of the previous block row has read the staging areas
         float* O = &lds[part * kPartFloats + oc];
+        // one specialised copy of the block row's arithmetic per (gr, gc): the accumulators are used where they are
+        // (a switch per block instead made the compiler copy them into common registers first)
+        auto block_row = [&](auto GR, auto GC) {
 #pragma unroll
-        for (int vv = 0; vv < 4; ++vv) {
-            const int v = by * 4 + vv;
-            const int bx = vv + 4 * lh;
-            float M[3][3];
+            for (int vv = 0; vv < 4; ++vv) {
+                const int v = by * 4 + vv;
+                const int bx = vv + 4 * lh;
+                float M[3][3];
 #pragma unroll
-            for (int f = 0; f < 9; ++f) M[f / 3][f % 3] = acc[f][v];
-            float Y[4][4];
-            switch (part) {
-                case 0: inverse_part<0, 0>(M, Y); break;
-                case 1: inverse_part<0, 1>(M, Y); break;
-                case 2: inverse_part<1, 0>(M, Y); break;
-                default: inverse_part<1, 1>(M, Y); break;
+                for (int f = 0; f < 9; ++f) M[f / 3][f % 3] = acc[f][v];
+                float Y[4][4];
+                inverse_part<decltype(GR)::value, decltype(GC)::value>(M, Y);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) O[(r * 32 + bx * 4 + c) * kOS] = Y[r][c];
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) O[(r * 32 + bx * 4 + c) * kOS] = Y[r][c];
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        switch (part) {
+            case 0: block_row(I0{}, I0{}); break;
+            case 1: block_row(I0{}, I1{}); break;
+            case 2: block_row(I1{}, I0{}); break;
+            default: block_row(I1{}, I1{}); break;
         }
         __syncthreads();
         floatx4 vals[kIters];
