@@ -69,6 +69,9 @@ int ocrhip_destroy(ocrhip_handle h);
  *   0: a direct implicit GEMM (a float32 fma chain over the taps and channels).
  *   "lstm_persistent": 1 (default) runs the recurrence of a BiLSTM layer as one launch of persistent workgroups
  *   (W_hh resident in LDS, h_t handed over through L2); 0 launches one kernel per time step.  Same arithmetic.
+ *   "wino4_split": 1 (default) runs the F(4x4,3x3) layers with >= 256 input channels as two kernels (transform the
+ *   input tiles once into a workspace, then multiply from it); 0 keeps them fused (every 64-channel workgroup transforms
+ *   its tile itself).  Same arithmetic, identical results.
  *   "flat_gemm": 1 (default) runs the Dense layers, the LSTM input projections and the 2x2 convolutions as a flat
  *   GEMM with 256 x 128 tiles; 0 runs them on the implicit-GEMM convolution kernel (256 x 64 / spatial tiles).  Same
  *   arithmetic (a float32 fma chain over k in both). */

@@ -37,6 +37,12 @@ void set_lstm_persistent(int on) { g_lstm_persistent = on; }
 static thread_local int g_conv3x3_winograd = 2;
 int conv3x3_winograd() { return g_conv3x3_winograd; }
 void set_conv3x3_winograd(int on) { g_conv3x3_winograd = on; }
+static thread_local DevBuf* g_workspace = nullptr;
+DevBuf* current_workspace() { return g_workspace; }
+void set_current_workspace(DevBuf* ws) { g_workspace = ws; }
+static thread_local int g_wino4_split = 1;
+int wino4_split() { return g_wino4_split; }
+void set_wino4_split(int on) { g_wino4_split = on; }
 static thread_local int g_flat_gemm = 1;
 int flat_gemm() { return g_flat_gemm; }
 void set_flat_gemm(int on) { g_flat_gemm = on; }
@@ -242,6 +248,8 @@ using namespace ocrhip;
         ocrhip::set_conv3x3_winograd((h)->conv3x3_winograd);        \
         ocrhip::set_lstm_persistent((h)->lstm_persistent);          \
         ocrhip::set_flat_gemm((h)->flat_gemm);                      \
+        ocrhip::set_current_workspace(&(h)->wino_ws);               \
+        ocrhip::set_wino4_split((h)->wino4_split);                  \
     } while (0)
 
 extern "C" {
@@ -294,6 +302,8 @@ int ocrhip_destroy(ocrhip_handle h) {
     h->crnn.ring.release();
     h->decode_stage.release();
     h->lanms_ws.release();
+    h->wino_ws.release();
+    ocrhip::set_current_workspace(nullptr);
     h->prof.recycle();
     for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
     ocrhip::set_current_profiler(nullptr);
@@ -822,6 +832,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "lstm_persistent") == 0) {
         OCR_REQUIRE(value == 0 || value == 1, "set_option: lstm_persistent is 0 or 1");
         h->lstm_persistent = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "wino4_split") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: wino4_split is 0 or 1");
+        h->wino4_split = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "flat_gemm") == 0) {

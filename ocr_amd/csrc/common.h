@@ -149,6 +149,8 @@ struct ocrhip_ctx {
     ocrhip::DevBuf lanms_ws;       // scratch of the LANMS kernel
     int lstm_persistent = 1;       // recurrence of a BiLSTM layer in one persistent launch (1) or one launch per step (0)
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
+    int wino4_split = 1;           // F(4x4,3x3) layers with >= 256 input channels: transform once into `wino_ws`, multiply from it (1) or fused (0)
+    ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
     int flat_gemm = 1;             // 1x1 / 2x2 layers on the 256 x 128 flat GEMM (1) or on the implicit-GEMM convolution kernel (0)
     ocrhip::Profiler prof;
 };
@@ -185,6 +187,10 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin);
 bool conv_wino4_fits(const ConvLayer& L, int H, int W, int pool);
 int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
                       const float* residual, hipStream_t s);
+DevBuf* current_workspace();         // grow-only scratch of the handle in use on this thread (transformed tiles), or nullptr
+void set_current_workspace(DevBuf* ws);
+int wino4_split();                   // option of the handle in use on this thread
+void set_wino4_split(int on);
 int conv3x3_winograd();              // option of the handle in use on this thread
 void set_conv3x3_winograd(int on);
 

@@ -60,6 +60,8 @@ struct Wino4Args {
     float* y;
     int B, H, W, cin, cout, relu;
     int tiles_x, tiles_per_image, n_blocks_n;
+    float* v;              // MODE 1 / 2: transformed tiles [tile][chunk][36][32 blocks][8], laid out like U in LDS
+    int chunks_per_group;  // MODE 1: chunks a workgroup transforms
     int pair;              // 1: images of 8 rows, two of them stacked in one tile (rows 0..7 and 8..15 of its outputs)
 };
 
@@ -95,7 +97,15 @@ __device__ __forceinline__ void inverse_part(const float (&M)[3][3], float (&Y)[
     }
 }
 
-template <int POOL>
+// MODE 0: the fused kernel described above.  MODE 1 and 2 split it for deep layers (>= 256 input channels), where the
+// data transform - repeated by each of the Cout / 64 workgroups of a tile and paid for in MFMA issue time - weighs
+// more than writing the transformed tile to memory once:
+//   MODE 1 transforms only: a workgroup owns a tile and a group of chunks (the `channel block` index of the grid) and
+//          writes U[chunk] (the 36 KB LDS image) to the workspace v;
+//   MODE 2 multiplies only: the MFMA operands of both sides come straight from memory (v and the filter slab, 16 bytes
+//          per lane, reloaded for the next chunk right after their last use): no LDS, no barrier and no vector-ALU work
+//          in the chunk loop; LDS serves the epilogue alone.
+template <int POOL, int MODE>
 __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // U[2] then raw[2]: chunk j lives in buffer j & 1
 
@@ -119,7 +129,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     // bias now: a load still in flight in the epilogue would stall its guarded stores
     const int c4 = tid & 15;
     const int co0 = nb * 64 + c4 * 4;
-    const floatx4 bias4 = *reinterpret_cast<const floatx4*>(a.bias + co0);          // bias is padded to cout_pad
+    floatx4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE != 1) bias4 = *reinterpret_cast<const floatx4*>(a.bias + co0);          // bias is padded to cout_pad
 
     floatx16 acc[9];
 #pragma unroll
@@ -218,15 +229,64 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         if (wave < 4) transform_task(8 + wave, rbase, ubase);
     };
 
-    float4 bw[9], af[3];
+    float4 bw[9], af[MODE == 2 ? 9 : 3];
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.v + (int64_t)tile_all * nK * kUFloats), 0, MODE == 0 ? 0 : nK * kUFloats * 4, 0x00020000);
     const int u_src = ((3 * gr) * 6 + 3 * gc) * kUC + li * kCK + ((lh ^ ((li >> 3) & 1)) * 4);
     auto af_read = [&](int ubase, int g) {       // component row 3 gr + g, columns 3 gc + 0..2
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) af[jj] = *reinterpret_cast<const float4*>(&lds[ubase + u_src + (g * 6 + jj) * kUC]);
     };
 
-    // prologue: chunk 0 transformed into U[0], raw tile 1 in raw[1], raw tile 2 on its way, filter fragments of chunk 0
     constexpr int kR0 = 2 * kUFloats, kR1 = 2 * kUFloats + kRBuf;
+    if constexpr (MODE == 1) {
+        // transform only: chunks [nb * chunks_per_group, ...) of this tile -> v
+        const int k_lo = nb * a.chunks_per_group, k_hi = min(nK, k_lo + a.chunks_per_group);
+        load_raw(k_lo);
+        for (int kc = k_lo; kc < k_hi; ++kc) {
+            store_raw(kR0);
+            if (kc + 1 < k_hi) load_raw(kc + 1);
+            __syncthreads();
+            transform(kR0, 0);
+            __syncthreads();
+            float4* dstv = reinterpret_cast<float4*>(a.v + ((int64_t)tile_all * nK + kc) * kUFloats);
+            for (int f = tid; f < kUFloats / 4; f += 512) dstv[f] = *reinterpret_cast<const float4*>(&lds[f * 4]);
+        }
+        return;
+    }
+    auto load_v = [&](int kc, int f) {          // A fragment of component (3 gr + f / 3, 3 gc + f % 3) of chunk kc from v
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, u_src * 4, kc * (kUFloats * 4) + ((f / 3) * 6 + f % 3) * (kUC * 4), 0));
+    };
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int f = 0; f < 9; ++f) {
+            af[f] = load_v(0, f);
+            bw[f] = load_w(0, f);
+        }
+        for (int kc = 0; kc < nK; ++kc) {
+            const int kn = min(kc + 1, nK - 1);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) {
+                        const float4 a4 = af[g * 3 + jj], b4 = bw[g * 3 + jj];
+                        const float av = t == 0 ? a4.x : (t == 1 ? a4.y : (t == 2 ? a4.z : a4.w));
+                        const float bv = t == 0 ? b4.x : (t == 1 ? b4.y : (t == 2 ? b4.z : b4.w));
+                        acc[g * 3 + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g * 3 + jj], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    af[g * 3 + jj] = load_v(kn, g * 3 + jj);
+                    bw[g * 3 + jj] = load_w(kn, g * 3 + jj);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // MODE 0 prologue: chunk 0 transformed into U[0], raw tile 1 in raw[1], raw tile 2 on its way, filter fragments of chunk 0
+    if constexpr (MODE == 0) {
     {
         float4 rb[NRAW];                         // raw tiles 0 and 1 requested together: one memory round trip
         load_raw(0);
@@ -279,6 +339,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         chunk(kc, std::integral_constant<int, 0>{});
         chunk(kc + 1, std::integral_constant<int, 1>{});
     }
+    }       // MODE == 0
 
     // ---- inverse transform and output, one block row (4 x 32 outputs) at a time.  Register v of a lane belongs to block
     // m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5), i.e. block row v >> 2, and to output channel lane & 31 of the wave's 32.
@@ -429,7 +490,11 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * (a.pair ? (B + 1) / 2 : B);
     OCR_REQUIRE(wgs < (1ll << 31), "conv_wino4: too many workgroups");
     char pname[64];
-    std::snprintf(pname, sizeof(pname), "conv_wino4_f32<n64,pool%d,tile16x32>", pool);
+    static const bool per_layer = getenv("OCRHIP_PROFILE_LAYERS") != nullptr;      // development aid: one profile line per layer shape
+    if (per_layer)
+        std::snprintf(pname, sizeof(pname), "conv_wino4_f32<p%d,c%d-%d,h%d>", pool, L.cin, L.cout, H);
+    else
+        std::snprintf(pname, sizeof(pname), "conv_wino4_f32<n64,pool%d,tile16x32>", pool);
     const double out_px = (double)B * H * W;
     const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : (pool == 2 ? 2.0 : 1.0));
     ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
@@ -438,18 +503,38 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     int dev = 0;
     OCR_HIP_CHECK(hipGetDevice(&dev));
     bool& lds_opt_in = lds_opt_in_dev[dev & 63];
+#define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2)
     if (!lds_opt_in) {
-        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+#define OCR_W4_OPT_IN(P, M)                                                                                               \
+    OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<P, M>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        OCR_W4_FOR_ALL(OCR_W4_OPT_IN)
+#undef OCR_W4_OPT_IN
         lds_opt_in = true;
     }
-    if (pool == 0)
-        hipLaunchKernelGGL((conv_wino4_f32_kernel<0>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
-    else if (pool == 1)
-        hipLaunchKernelGGL((conv_wino4_f32_kernel<1>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
-    else
-        hipLaunchKernelGGL((conv_wino4_f32_kernel<2>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
+    // Deep layers: transform once into the workspace, then multiply from it (see MODE 1 / 2 of the kernel)
+    DevBuf* ws = current_workspace();
+    const int nK = L.cin / kCK;
+    const int64_t tiles_total = (int64_t)a.tiles_per_image * (a.pair ? (B + 1) / 2 : B);
+    const int64_t v_bytes = tiles_total * nK * kUFloats * 4;
+    int mode = 0;
+    static const int split_min_cin = getenv("OCRHIP_SPLIT_MIN_CIN") ? atoi(getenv("OCRHIP_SPLIT_MIN_CIN")) : 256;      // development aid
+    if (ws && wino4_split() && L.cin >= split_min_cin && v_bytes <= (6ll << 30) && ws->reserve((size_t)v_bytes) == OCRHIP_OK) mode = 2;
+    a.v = mode ? ws->as<float>() : nullptr;
+    a.chunks_per_group = 8;
+    if (mode == 2) {
+        Wino4Args t = a;
+        t.n_blocks_n = (nK + t.chunks_per_group - 1) / t.chunks_per_group;
+        const int64_t twgs = tiles_total * t.n_blocks_n;
+        OCR_REQUIRE(twgs < (1ll << 31), "conv_wino4: too many workgroups");
+        hipLaunchKernelGGL((conv_wino4_f32_kernel<0, 1>), dim3((unsigned)twgs), dim3(512), kLdsBytes, s, t);
+    }
+#define OCR_W4_LAUNCH(P, M)                                                                                               \
+    if (pool == P && mode == M && M != 1)                                                                                 \
+        hipLaunchKernelGGL((conv_wino4_f32_kernel<P, M>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
+    OCR_W4_FOR_ALL(OCR_W4_LAUNCH)
+#undef OCR_W4_LAUNCH
+#undef OCR_W4_FOR_ALL
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }

@@ -165,8 +165,12 @@ def test_direct_3x3_path_matches_oracle_too(ctx, shape):
             maps[opt] = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
             got = ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True)['logits'].cpu().numpy()
             _close(got, cref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(cref).max())))
+        ctx.set_option('wino4_split', 0)          # deep layers fused instead of transform kernel + multiply kernel
+        fused = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
     finally:
         ctx.set_option('conv3x3_winograd', 2)
+        ctx.set_option('wino4_split', 1)
+    np.testing.assert_array_equal(fused, maps[2])     # same products in the same order
     for opt in (0, 1, 2):
         _close(maps[opt], ref, rtol=1e-4, atol=1e-5)
     _close(maps[1], maps[0], rtol=1e-4, atol=1e-5)
