@@ -489,16 +489,6 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     a.n_blocks_n = L.cout_pad / 64;
     const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * (a.pair ? (B + 1) / 2 : B);
     OCR_REQUIRE(wgs < (1ll << 31), "conv_wino4: too many workgroups");
-    char pname[64];
-    static const bool per_layer = getenv("OCRHIP_PROFILE_LAYERS") != nullptr;      // development aid: one profile line per layer shape
-    if (per_layer)
-        std::snprintf(pname, sizeof(pname), "conv_wino4_f32<p%d,c%d-%d,h%d>", pool, L.cin, L.cout, H);
-    else
-        std::snprintf(pname, sizeof(pname), "conv_wino4_f32<n64,pool%d,tile16x32>", pool);
-    const double out_px = (double)B * H * W;
-    const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : (pool == 2 ? 2.0 : 1.0));
-    ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
-                   4.0 * (out_px * L.cin + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout), s);
     static bool lds_opt_in_dev[64] = {};        // more than 64 KB of LDS per workgroup needs an opt-in per kernel and device
     int dev = 0;
     OCR_HIP_CHECK(hipGetDevice(&dev));
@@ -522,13 +512,25 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     if (ws && wino4_split() && L.cin >= split_min_cin && v_bytes <= (6ll << 30) && ws->reserve((size_t)v_bytes) == OCRHIP_OK) mode = 2;
     a.v = mode ? ws->as<float>() : nullptr;
     a.chunks_per_group = 8;
+    const double out_px = (double)B * H * W;
+    const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : (pool == 2 ? 2.0 : 1.0));
     if (mode == 2) {
         Wino4Args t = a;
         t.n_blocks_n = (nK + t.chunks_per_group - 1) / t.chunks_per_group;
         const int64_t twgs = tiles_total * t.n_blocks_n;
         OCR_REQUIRE(twgs < (1ll << 31), "conv_wino4: too many workgroups");
+        ProfScope prof("conv_wino4_transform", 0.0, 4.0 * out_px * L.cin + (double)v_bytes, s);      // HBM bound: input read, tiles written
         hipLaunchKernelGGL((conv_wino4_f32_kernel<0, 1>), dim3((unsigned)twgs), dim3(512), kLdsBytes, s, t);
     }
+    // profile name: the fused kernel and the multiply-only kernel are different kernels
+    char pname[64];
+    static const bool per_layer = getenv("OCRHIP_PROFILE_LAYERS") != nullptr;      // development aid: one profile line per layer shape
+    if (per_layer)
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<p%d,c%d-%d,h%d>", mode == 2 ? "_mul" : "", pool, L.cin, L.cout, H);
+    else
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<n64,pool%d,tile16x32>", mode == 2 ? "_mul" : "", pool);
+    ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
+                   4.0 * ((mode == 2 ? 0.0 : out_px * L.cin) + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout) + (mode == 2 ? (double)v_bytes : 0.0), s);
 #define OCR_W4_LAUNCH(P, M)                                                                                               \
     if (pool == P && mode == M && M != 1)                                                                                 \
         hipLaunchKernelGGL((conv_wino4_f32_kernel<P, M>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);

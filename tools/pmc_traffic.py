@@ -22,9 +22,11 @@ def stage_name(kernel):
         rows, cols = (256, 1) if ks == 1 else (4 * mt * (32 // tw), tw)
         return 'conv_mfma_f32<ks%d,n%d,pool%s,up%d,tile%dx%d>' % (ks, 32 * int(m.group(2)), m.group(3),
                                                                   m.group(4) == 'true', rows, cols)
-    m = re.search(r'conv_wino4_f32_kernel<(\d+)>', kernel)
+    m = re.search(r'conv_wino4_f32_kernel<(\d+), (\d+)>', kernel)
     if m:
-        return 'conv_wino4_f32<n64,pool%s,tile16x32>' % m.group(1)
+        if m.group(2) == '1':
+            return 'conv_wino4_transform'
+        return 'conv_wino4%s_f32<n64,pool%s,tile16x32>' % ('_mul' if m.group(2) == '2' else '', m.group(1))
     m = re.search(r'lstm_layer_kernel', kernel)
     if m:
         return 'lstm_layer'
