@@ -132,6 +132,22 @@ int ocrhip_east_decode(ocrhip_handle h, const float* d_maps, int B, int mh, int 
                        float obj_threshold, int cap, float* d_xyxy, float* d_polys, float* d_scores,
                        int* d_pix, int* d_counts, ocrhip_stream stream);
 
+/* ocrhip_east_decode for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for
+ * bit; the difference is where the kernels' staging area lives (the per-wave survivor masks and per-chunk counts
+ * the two decode kernels hand to each other): ocrhip_east_decode keeps it in a grow-only buffer of the handle
+ * (hipMalloc when a call needs more than any call before it), this entry point keeps it in a fixed 1.125 MB array in
+ * device memory that every GPU the library runs on holds until the process ends.  The call makes no hipMalloc /
+ * hipFree / event creation and records no stage timer.
+ *   Limit: B * ceil(mh*mw / 256) <= 32768 (8.4 M map pixels per call, e.g. 128 pages of 1024x1024); beyond it
+ *   the call returns OCRHIP_ECAP and launches nothing.
+ *   All handles and streams of one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ *   host threads) race on it; serialise them or use ocrhip_east_decode.  Nothing in the array has to start at zero
+ *   (the first kernel writes every word the second reads), so a call is not disturbed by what the last one left. */
+int ocrhip_east_decode_static(ocrhip_handle h, const float* d_maps, int B, int mh, int mw, int in_h, int in_w,
+                              float obj_threshold, int cap, float* d_xyxy, float* d_polys, float* d_scores,
+                              int* d_pix, int* d_counts, ocrhip_stream stream);
+
 /* Locality-aware NMS followed (when nms_threshold < merge_threshold) by matrix NMS.  Replaces
  * lanms / self_merging / _merge_boxes (utils/image/bounding_box/locality_aware_nms.py:22-126),
  * fast_nms / self_suppression (non_max_suppression.py:117-138,191-220) and _sort_boxes (:247-253).

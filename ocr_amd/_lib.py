@@ -38,6 +38,8 @@ SIGNATURES = {
     'ocrhip_east_get_activation': (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64)]),
     'ocrhip_east_decode': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ocrhip_east_decode_static': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ocrhip_lanms': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_int,
                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ocrhip_crop_resize_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

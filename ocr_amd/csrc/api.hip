@@ -270,6 +270,7 @@ int ocrhip_create(int device, ocrhip_handle* out) {
         set_error("create: device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
         return OCRHIP_ESTATE;
     }
+    OCR_TRY(decode_static_init(device));
     ocrhip_ctx* h = new ocrhip_ctx();
     h->device = device;
     *out = h;
@@ -448,6 +449,16 @@ int ocrhip_east_decode(ocrhip_handle h, const float* d_maps, int B, int mh, int 
     OCR_HANDLE(h);
     return launch_east_decode(h, d_maps, B, mh, mw, in_h, in_w, obj_threshold, cap, d_xyxy, d_polys, d_scores, d_pix,
                               d_counts, (hipStream_t)stream);
+}
+
+int ocrhip_east_decode_static(ocrhip_handle h, const float* d_maps, int B, int mh, int mw, int in_h, int in_w,
+                              float obj_threshold, int cap, float* d_xyxy, float* d_polys, float* d_scores, int* d_pix,
+                              int* d_counts, ocrhip_stream stream) {
+    // no OCR_HANDLE: nothing here may create events or touch the handle's buffers
+    OCR_REQUIRE(h, "east_decode_static: null handle");
+    OCR_HIP_CHECK(hipSetDevice(h->device));
+    return launch_east_decode_static(h, d_maps, B, mh, mw, in_h, in_w, obj_threshold, cap, d_xyxy, d_polys, d_scores,
+                                     d_pix, d_counts, (hipStream_t)stream);
 }
 
 int ocrhip_lanms(ocrhip_handle h, const float* d_xyxy, const float* d_scores, const int* d_counts, int B, int cap,

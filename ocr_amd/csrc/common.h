@@ -211,6 +211,13 @@ int launch_east_heads(const ConvLayer& L, const float* x, float* maps, int64_t n
 int launch_east_decode(ocrhip_ctx* h, const float* maps, int B, int mh, int mw, int in_h, int in_w, float thr,
                        int cap, float* xyxy, float* polys, float* scores, int* pix, int* counts, hipStream_t s);
 
+// decode.hip: the same decode with its staging area in a fixed device array instead of the handle's grow-only buffer
+// (no allocation in the call; ECAP beyond the array's size).  decode_static_init looks the array's address up once per
+// device (ocrhip_create calls it with that device current).
+int decode_static_init(int device);
+int launch_east_decode_static(ocrhip_ctx* h, const float* maps, int B, int mh, int mw, int in_h, int in_w, float thr,
+                              int cap, float* xyxy, float* polys, float* scores, int* pix, int* counts, hipStream_t s);
+
 // lanms.hip
 int launch_lanms(ocrhip_ctx* h, const float* xyxy, const float* scores, const int* counts, int B, int cap,
                  float merge_thr, float nms_thr, int merge_method, int max_iter, int max_out, float* merged,

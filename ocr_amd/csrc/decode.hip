@@ -13,6 +13,8 @@
 //      pixels are decoded again (same code, same bits) and written at their final position.
 // HBM traffic: the 24 B/pixel map once, plus the cache lines of surviving pixels a second time,
 // plus 36 B (68 B with polygons) per box written.
+#include <mutex>
+
 #include "common.h"
 
 namespace ocrhip {
@@ -160,29 +162,96 @@ __global__ __launch_bounds__(kChunk) void east_decode_write(const float* __restr
 
 }  // namespace
 
-int launch_east_decode(ocrhip_ctx* h, const float* maps, int B, int mh, int mw, int in_h, int in_w, float thr,
-                       int cap, float* xyxy, float* polys, float* scores, int* pix, int* counts, hipStream_t s) {
+// Checks the arguments both entry points share and sizes the staging area: (B, nchunks, 4) 64-bit masks followed
+// by (B, nchunks) int32 counts.
+static int decode_check(const float* maps, int B, int mh, int mw, int in_h, int in_w, int cap, const float* xyxy,
+                        const float* scores, const int* counts, int* nchunks, size_t* mask_bytes, size_t* count_bytes) {
     OCR_REQUIRE(maps && xyxy && scores && counts, "east_decode: maps, xyxy, scores and counts are required");
     OCR_REQUIRE(B >= 0 && mh > 0 && mw > 0 && cap > 0, "east_decode: bad sizes B=%d mh=%d mw=%d cap=%d", B, mh, mw, cap);
     OCR_REQUIRE(in_h >= mh && in_w >= mw && in_h % mh == 0 && in_w % mw == 0,
                 "east_decode: input %dx%d is not an integer multiple of the map %dx%d", in_h, in_w, mh, mw);
     OCR_REQUIRE((int64_t)mh * mw < (1ll << 30), "east_decode: map too large");
-    if (B == 0) return OCRHIP_OK;
     const int npix = mh * mw;
-    const int nchunks = (npix + kChunk - 1) / kChunk;
-    const size_t mask_bytes = (size_t)B * nchunks * 4 * sizeof(unsigned long long);
-    const size_t count_bytes = (size_t)B * nchunks * sizeof(int);
-    OCR_TRY(h->decode_stage.reserve(mask_bytes + count_bytes));
-    auto* masks = h->decode_stage.as<unsigned long long>();
-    int* chunk_counts = reinterpret_cast<int*>(reinterpret_cast<char*>(h->decode_stage.ptr) + mask_bytes);
+    *nchunks = (npix + kChunk - 1) / kChunk;
+    *mask_bytes = (size_t)B * *nchunks * 4 * sizeof(unsigned long long);
+    *count_bytes = (size_t)B * *nchunks * sizeof(int);
+    return OCRHIP_OK;
+}
+
+// Both kernels over a staging area of mask_bytes + count_bytes bytes.  The first kernel writes every mask and
+// every count the second one reads, so the staging area needs no initialisation.
+static int decode_enqueue(void* stage, size_t mask_bytes, int nchunks, const float* maps, int B, int mh, int mw, int in_h,
+                          int in_w, float thr, int cap, float* xyxy, float* polys, float* scores, int* pix, int* counts,
+                          hipStream_t s) {
+    auto* masks = reinterpret_cast<unsigned long long*>(stage);
+    int* chunk_counts = reinterpret_cast<int*>(reinterpret_cast<char*>(stage) + mask_bytes);
     dim3 grid(nchunks, B), block(kChunk);
-    // algorithmic bytes: the 24 B/pixel map; the 36 B (+32 B polygon) per box depend on the data
-    ProfScope prof("east_decode", 0.0, 24.0 * (double)B * npix, s);
     hipLaunchKernelGGL(east_decode_flags, grid, block, 0, s, maps, mh, mw, in_h, in_w, thr, masks, chunk_counts);
     hipLaunchKernelGGL(east_decode_write, grid, block, 0, s, maps, mh, mw, in_h, in_w, masks, chunk_counts, cap, xyxy,
                        polys, scores, pix, counts);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
+}
+
+int launch_east_decode(ocrhip_ctx* h, const float* maps, int B, int mh, int mw, int in_h, int in_w, float thr,
+                       int cap, float* xyxy, float* polys, float* scores, int* pix, int* counts, hipStream_t s) {
+    int nchunks = 0;
+    size_t mask_bytes = 0, count_bytes = 0;
+    OCR_TRY(decode_check(maps, B, mh, mw, in_h, in_w, cap, xyxy, scores, counts, &nchunks, &mask_bytes, &count_bytes));
+    if (B == 0) return OCRHIP_OK;
+    OCR_TRY(h->decode_stage.reserve(mask_bytes + count_bytes));
+    // algorithmic bytes: the 24 B/pixel map; the 36 B (+32 B polygon) per box depend on the data
+    ProfScope prof("east_decode", 0.0, 24.0 * (double)B * mh * mw, s);
+    return decode_enqueue(h->decode_stage.ptr, mask_bytes, nchunks, maps, B, mh, mw, in_h, in_w, thr, cap, xyxy, polys,
+                          scores, pix, counts, s);
+}
+
+// ---- the same decode for callers that must not allocate ---------------------------------------------------------
+// The staging area is a fixed array in device memory: every GPU the library runs on holds its own copy at its own
+// address until the process ends.  kStaticChunks chunks of 256 map pixels = 8.4 M map pixels per call (128 pages of
+// 1024 x 1024, whose maps are 256 x 256), 36 bytes of staging per chunk.
+constexpr int kStaticChunks = 32768;
+constexpr size_t kStaticBytes = (size_t)kStaticChunks * (4 * sizeof(unsigned long long) + sizeof(int));
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];          // device address of `scratch` on each GPU, set by decode_static_init
+static std::mutex g_scratch_mutex;
+
+// Called by ocrhip_create with `device` current: looks up the address of this GPU's copy of the array once.
+int decode_static_init(int device) {
+    OCR_REQUIRE(device >= 0 && device < kMaxDevices, "create: device index %d is beyond the %d this library tracks", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return OCRHIP_OK;
+    void* ptr = nullptr;
+    OCR_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    OCR_REQUIRE(ptr != nullptr, "create: the static staging array has no address on device %d", device);
+    g_scratch_ptr[device] = ptr;
+    return OCRHIP_OK;
+}
+
+int launch_east_decode_static(ocrhip_ctx* h, const float* maps, int B, int mh, int mw, int in_h, int in_w, float thr,
+                              int cap, float* xyxy, float* polys, float* scores, int* pix, int* counts, hipStream_t s) {
+    int nchunks = 0;
+    size_t mask_bytes = 0, count_bytes = 0;
+    OCR_TRY(decode_check(maps, B, mh, mw, in_h, in_w, cap, xyxy, scores, counts, &nchunks, &mask_bytes, &count_bytes));
+    if ((int64_t)B * nchunks > kStaticChunks) {
+        set_error("east_decode_static: %d maps of %dx%d need %lld chunks of %d pixels, the static staging area holds %d "
+                  "(use ocrhip_east_decode or fewer pages per call)", B, mh, mw, (long long)B * nchunks, kChunk, kStaticChunks);
+        return OCRHIP_ECAP;
+    }
+    if (B == 0) return OCRHIP_OK;
+    void* stage = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        stage = (h->device >= 0 && h->device < kMaxDevices) ? g_scratch_ptr[h->device] : nullptr;
+    }
+    if (!stage) {
+        set_error("east_decode_static: the static staging area of device %d was not set up", h->device);
+        return OCRHIP_ESTATE;
+    }
+    return decode_enqueue(stage, mask_bytes, nchunks, maps, B, mh, mw, in_h, in_w, thr, cap, xyxy, polys, scores, pix,
+                          counts, s);
 }
 
 }  // namespace ocrhip
