@@ -75,3 +75,53 @@ class CharTokenizer:
     def ctc_decode(self, logits, lengths=None):
         tokens, scores = ctc_greedy(logits, lengths, self.blank_token_idx)
         return [self.decode(t) for t in tokens], scores
+
+
+def tie_flips(ref_logits, got_text, tokenizer, rel_tol=1e-4, max_ties=14):
+    """Is `got_text` a greedy decoding of `ref_logits` (T,V) apart from argmax ties?
+
+    A step is a tie when the two largest logits of the step differ by less than `rel_tol` times the
+    largest magnitude in `ref_logits` (the tolerance the network outputs are held to).  Returns the
+    smallest number of tie steps at which the runner-up has to be taken to produce `got_text`
+    (0 = the plain greedy decoding), or None when no choice at the tie steps produces it.
+    """
+    ref_logits = np.asarray(ref_logits, dtype=np.float32)
+    order = np.argsort(-ref_logits, axis=1, kind='stable')[:, :2]
+    top = np.take_along_axis(ref_logits, order, axis=1)
+    tol = np.float32(rel_tol) * np.abs(ref_logits).max()
+    ties = np.nonzero((top[:, 0] - top[:, 1]) < tol)[0]
+    if len(ties) > max_ties:
+        ties = ties[np.argsort((top[:, 0] - top[:, 1])[ties])[:max_ties]]
+    blank = tokenizer.blank_token_idx
+    best = None
+    for choice in range(1 << len(ties)):
+        n_flips = bin(choice).count('1')
+        if best is not None and n_flips >= best:
+            continue
+        ids = order[:, 0].copy()
+        for j, t in enumerate(ties):
+            if (choice >> j) & 1:
+                ids[t] = order[t, 1]
+        prev, toks = -1, []
+        for t in ids:
+            if t != prev and t != blank:
+                toks.append(int(t))
+            prev = t
+        if tokenizer.decode(toks + [-1]) == got_text:
+            best = n_flips
+    return best
+
+
+def assert_texts_match_or_tie(got_texts, ref_texts, ref_logits, tokenizer, rel_tol=1e-4):
+    """Every string equals the oracle's, or differs from it only through argmax ties of the oracle's own
+    logits (`tie_flips`).  `ref_logits[k]` are the (T_k,V) logits the oracle decoded string k from.
+    Returns the number of strings that needed a tie flip."""
+    assert len(got_texts) == len(ref_texts), (len(got_texts), len(ref_texts))
+    flipped = 0
+    for k, (g, r) in enumerate(zip(got_texts, ref_texts)):
+        if g == r:
+            continue
+        n = tie_flips(ref_logits[k], g, tokenizer, rel_tol)
+        assert n is not None and n > 0, 'string %d: %r differs from the oracle\'s %r and no argmax tie explains it' % (k, g, r)
+        flipped += 1
+    return flipped

@@ -30,8 +30,9 @@ def detect_page(image_u8, east_params, maps_override=None, obj_threshold=0.35, n
     return maps, boxes[mask], scores[mask]
 
 
-def recognise_rows(image_u8, boxes_rel, crnn_params, tokenizer):
-    """One forward per row (batch 1), as base_ocr.py:171-201; empty inputs are skipped (:182-184)."""
+def recognise_rows(image_u8, boxes_rel, crnn_params, tokenizer, return_logits=False):
+    """One forward per row (batch 1), as base_ocr.py:171-201; empty inputs are skipped (:182-184).
+    `return_logits` adds the list of per-row (T_i,V) logits as a fourth result."""
     outputs, index = [], []
     for i, box in enumerate(boxes_rel):
         _, crop = obox.crop_box(image_u8, box)
@@ -41,17 +42,20 @@ def recognise_rows(image_u8, boxes_rel, crnn_params, tokenizer):
         outputs.append(nets.crnn_forward(crnn_params, inp[None])[0].numpy())
         index.append(i)
     if not outputs:
-        return [], [], np.zeros((0,), np.float32)
+        return ([], [], np.zeros((0,), np.float32)) + (([],) if return_logits else ())
     lengths = np.array([len(o) for o in outputs], dtype=np.int32)
     tmax, v = int(lengths.max()), outputs[0].shape[1]
     padded = np.zeros((len(outputs), tmax, v), dtype=np.float32)      # pad_batch(pad_value=0.)
     for k, o in enumerate(outputs):
         padded[k, :len(o)] = o
     texts, scores = tokenizer.ctc_decode(padded, lengths)
+    if return_logits:
+        return index, texts, scores, outputs
     return index, texts, scores
 
 
 def ocr_page(image_u8, east_params, crnn_params, tokenizer, maps_override=None, **kw):
+    """`logits`: the per-row (T_i,V) logits the strings were decoded from (for tie checks)."""
     _, boxes, _ = detect_page(image_u8, east_params, maps_override, **kw)
-    index, texts, scores = recognise_rows(image_u8, boxes, crnn_params, tokenizer)
-    return {'boxes': boxes, 'index': index, 'texts': texts, 'scores': scores}
+    index, texts, scores, logits = recognise_rows(image_u8, boxes, crnn_params, tokenizer, return_logits=True)
+    return {'boxes': boxes, 'index': index, 'texts': texts, 'scores': scores, 'logits': logits}

@@ -33,9 +33,9 @@ def test_pipeline_matches_cpu_reference_path():
         np.testing.assert_array_equal(got[b]['boxes'], ref['boxes'])
         assert list(np.nonzero(got[b]['valid'])[0]) == list(ref['index'])
         got_texts = [got[b]['texts'][i] for i in ref['index']]
-        mism = [(g, r) for g, r in zip(got_texts, ref['texts']) if g != r]
-        # random weights leave tiny argmax margins: allow a documented handful of near-tie flips
-        assert len(mism) <= max(1, len(ref['texts']) // 20), mism
+        # identical strings; a string may differ only where the oracle's own logits have an argmax tie (two largest
+        # logits of a step within 1e-4 of the logit scale) and taking the runner-up there reproduces it
+        octc.assert_texts_match_or_tie(got_texts, ref['texts'], ref['logits'], tok)
         np.testing.assert_allclose([got[b]['scores'][i] for i in ref['index']], ref['scores'], rtol=1e-3, atol=1e-3)
         n_words += len(ref['texts'])
     assert n_words >= 20

@@ -44,13 +44,29 @@ def test_decode_golden_maps(ctx, golden, k):
     np.testing.assert_array_equal(got['polys'][0, :n], ref['boxes'])
     np.testing.assert_array_equal(got['scores'][0, :n], ref['scores'])
     np.testing.assert_array_equal(got['xyxy'][0, :n], obox.poly_to_xyxy(ref['boxes']))
-    # against the reference's own output (its sin/cos are NumPy float32: at most 1 ulp away)
-    gold = canonical_order(golden['decode%d_polys' % k], golden['decode%d_scores' % k])
-    mine = canonical_order(got['polys'][0, :n], got['scores'][0, :n])
-    if gold.shape == mine.shape:
-        np.testing.assert_allclose(mine, gold, rtol=0, atol=2e-6)
-    else:
-        assert abs(len(gold) - len(mine)) <= 2
+    # Against the reference's own output.  Its sin/cos are NumPy float32 loops, at most 1 ulp away from the
+    # correctly rounded values used here, so a box whose corner sits within rounding of the page border may pass
+    # the validity filter on one side only.  The oracle's 'numpy32' mode IS the reference's output bit for bit
+    # (asserted here as a set) and carries the map pixel of every box: boxes are matched by pixel, the symmetric
+    # difference is at most 2 boxes, and EVERY common box is compared.
+    gold = east_decode.decode_map(m, (h * 4, w * 4), trig='numpy32', return_index=True)
+    np.testing.assert_array_equal(canonical_order(gold['boxes'], gold['scores']),
+                                  canonical_order(golden['decode%d_polys' % k], golden['decode%d_scores' % k]))
+    common, ig, ir = np.intersect1d(got['pix'][0, :n], gold['index'], return_indices=True)
+    assert (n - len(common)) + (len(gold['index']) - len(common)) <= 2
+    assert len(common) >= 0.99 * len(gold['index']) > 0
+    np.testing.assert_allclose(got['polys'][0, :n][ig], gold['boxes'][ir], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(got['scores'][0, :n][ig], gold['scores'][ir])
+    np.testing.assert_allclose(got['xyxy'][0, :n][ig], golden_xyxy_by_pixel(golden, k, gold)[ir], rtol=0, atol=2e-6)
+
+
+def golden_xyxy_by_pixel(golden, k, gold):
+    """The reference's own poly -> xyxy output re-ordered to the order of `gold` (oracle 'numpy32' decode, equal to the
+    reference's polygons as a set): rows are matched on the polygon + score bits."""
+    key = lambda polys, scores: [p.tobytes() + s.tobytes() for p, s in zip(polys.reshape(len(polys), -1), scores)]
+    where = {kk: i for i, kk in enumerate(key(golden['decode%d_polys' % k], golden['decode%d_scores' % k]))}
+    rows = [where[kk] for kk in key(gold['boxes'], gold['scores'])]
+    return golden['decode%d_xyxy' % k][rows]
 
 
 def test_decode_batched_pages_and_edge_cases(ctx):
