@@ -1,26 +1,35 @@
-"""End-to-end OCR throughput on synthetic 1024x1024 dense-text pages (BASELINE.json config 4).
+"""End-to-end OCR throughput on synthetic dense-text pages (BASELINE.json config 4: 1024x1024).
 
     python bench.py --gpus 1 --steps 40 --warmup 3
+    python bench.py --gpus N ...            # starts its own N ranks (torch.distributed.run) when not already one of them
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the whole hot path over a batch of pages already resident in HBM:
 EAST-VGG16 forward (f32 MFMA) -> RBOX decode -> LANMS + NMS -> crop/resize/pack -> CRNN + CTC greedy
--> strings on the host.  Images are independent, so ranks share nothing (weak scaling, no
-collective in the data path; one barrier + one MAX all-reduce bracket the timed region).
+-> strings on the host.  Images are independent, so ranks share no data (weak scaling: N x steps
+batches per job, no collective in the data path).  The batches of the timed region sit in ONE queue
+all ranks take from (post-NMS word counts differ, a rank that is done early takes more), and every
+rank's boxes + strings are gathered on the host of rank 0 before the clock stops; one barrier and
+one MAX all-reduce (RCCL) bracket the timed region.
 
 No trained weights exist offline: both networks run with seeded random weights of the reference
 architectures (all their arithmetic is executed and timed), and the decode stage consumes the
 synthetic "teacher" maps of the rendered pages instead of the random-weight network output, so that
 decode / LANMS / crop / CRNN see realistic box counts (~18 000 candidates and ~200 words per page).
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the 3x3 f32-MFMA
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (a 3x3 f32-MFMA
 convolution), timed with HIP events on the launch stream inside the timed region by the library's
-stage timers; `cpu_baseline` times the reference-faithful CPU path (oracle/) on the host cores.
+stage timers: `achieved` / `frac` count the flops the matrix cores EXECUTE (a Winograd kernel
+executes 36/144 or 16/36 of the direct convolution's), `direct_equiv_tflops` the convolution it
+computes.  `roofline_hbm` lists the bandwidth-bound stages against 8 TB/s.  `cpu_baseline` times the
+reference-faithful CPU path (oracle/) on the host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,11 +52,30 @@ def parse():
     ap.add_argument('--batch', type=int, default=16, help='pages per step and per GPU')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--words', type=int, default=220)
+    ap.add_argument('--vocab', type=int, default=97, help='classes of the recogniser head (97 = english_g2, 6719 = zh_sim_g2)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32 = the reference's precision (the headline); bf16 = bfloat16 operands, float32 accumulation")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-pages', type=int, default=4)
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='rehearsal of the N-rank path on a box with fewer GPUs: rank r uses GPU r %% visible, gloo instead of '
+                         'RCCL for the two bracket collectives (RCCL refuses two ranks on one device), per-step LSTM kernel '
+                         '(the persistent one needs the whole GPU); the line it prints is not a scaling result')
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`--gpus N` outside torchrun: start N ranks as children of this process, which never touches a GPU itself."""
+    have = torch.cuda.device_count()          # counts devices without initialising the GPU runtime
+    if have < args.gpus and not (args.share_gpu and have >= 1):
+        sys.stderr.write('bench.py: --gpus %d asked for, %d GPU(s) visible\n' % (args.gpus, have))
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def cpu_baseline(images, maps, east_params, crnn_params, n_pages):
@@ -78,94 +106,187 @@ def pmc_traffic(kernel):
         return None
 
 
+def stage_accounting(pipe, d_img, d_maps):
+    """Data-dependent work of one batch for the bandwidth-bound stages (one untimed pass after the timed region):
+    decode candidates, LANMS pair tests, crop source / output pixels, CTC rows."""
+    from ocr_amd.utils import image_sizes as S
+    B, H, W, _ = d_img.shape
+    _, dec, kept = pipe.detect(d_img, d_maps)
+    torch.cuda.synchronize()
+    cand = dec['counts'].cpu().numpy().astype(np.int64)
+    n_iter = kept['n_iter'].cpu().numpy().astype(np.int64)
+    counts = kept['counts'].cpu().numpy()
+    boxes = kept['boxes'].cpu().numpy()
+    src_px = out_elems = ctc_rows = 0
+    for b in range(B):
+        p = S.plan_crops(boxes[b, :int(counts[b])], H, W)
+        r = p['rects'].astype(np.int64)
+        src_px += int(((r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1])).sum())
+        out_elems += int(64 * p['out_w'].astype(np.int64).sum())
+        ctc_rows += int(pipe.ctx.seq_len(p['out_w']).sum())
+    return {'decode_candidates': int(cand.sum()), 'decode_map_px': B * (H // 4) * (W // 4),
+            'lanms_pairs_first_iter': int((cand * cand).sum()), 'lanms_iters_max': int(n_iter.max(initial=0)),
+            'lanms_pairs_dense': int((cand * cand * n_iter).sum()), 'crop_src_px': src_px, 'crop_out_elems': out_elems,
+            'ctc_rows': ctc_rows}
+
+
+def hbm_rooflines(stats, acct, vocab, steps):
+    """Algorithmic bytes per launch of the bandwidth-bound stages / their HIP-event time, against 8 TB/s."""
+    by = {s['name']: s for s in stats}
+    per_launch = {
+        # 24 B x map pixels read + 20 B x boxes written (16 B xyxy + 4 B score; the pipeline asks for no polygons)
+        'east_decode': 24.0 * acct['decode_map_px'] + 20.0 * acct['decode_candidates'],
+        # 20 B per box in and out; the work is pair tests, not bytes
+        'lanms': 2 * 20.0 * acct['decode_candidates'],
+        # 3 B x crop source pixels read + 4 B x 64 x Wpad written
+        'crop_resize_pack': 3.0 * acct['crop_src_px'] + 4.0 * acct['crop_out_elems'],
+        # 4 B x T x V logits read + 4 B x T tokens written
+        'ctc_greedy': 4.0 * acct['ctc_rows'] * (vocab + 1),
+    }
+    pmc_names = {'east_decode': ['east_decode_flags', 'east_decode_write']}
+    out = []
+    for name, nbytes in per_launch.items():
+        s = by.get(name)
+        if not s or not s['launches']:
+            continue
+        avg_ms = s['total_ms'] / s['launches']
+        parts = [pmc_traffic(k) for k in pmc_names.get(name, [name])]
+        e = {'kernel': name, 'launches_per_step': s['launches'] / steps, 'algorithmic_bytes': nbytes, 'avg_ms': avg_ms,
+             'achieved_GBs': nbytes / (avg_ms * 1e-3) / 1e9, 'frac_of_8TBs': nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             'traffic': None if any(p is None for p in parts) else sum(parts)}
+        if name == 'lanms':
+            e['bound'] = 'latency / pair tests, not HBM'
+            e['pair_tests_first_iteration'] = acct['lanms_pairs_first_iter']
+            e['iterations_max'] = acct['lanms_iters_max']
+            e['dense_pairs_per_s'] = acct['lanms_pairs_dense'] / (avg_ms * 1e-3)
+        out.append(e)
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.share_gpu:
+        local_rank %= max(1, torch.cuda.device_count())
+    if local_rank >= torch.cuda.device_count():
+        sys.exit('bench.py: rank with LOCAL_RANK=%d has no GPU (%d visible)' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    from ocr_amd.dist import init_from_env, max_over_ranks
-    rank, world, dist = init_from_env('nccl', torch.device('cuda', local_rank))     # RCCL when launched by torchrun
+    from ocr_amd.dist import PageQueue, gather_results, init_from_env, max_over_ranks
+    device = torch.device('cuda', local_rank)
+    grp = init_from_env('gloo' if args.share_gpu else 'nccl', device)          # RCCL when launched as one of N ranks
+    rank, world, dist = grp
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but the job has %d rank(s)' % (args.gpus, world))
 
     from ocr_amd import synth
     from ocr_amd.pipeline import OcrPipeline
     from ocr_amd.weights import random_east_params, random_crnn_params
 
     east_params = random_east_params(seed=1)
-    crnn_params = random_crnn_params(vocab_size=97, seed=2)
+    crnn_params = random_crnn_params(vocab_size=args.vocab, seed=2)
     from ocr_amd._lib import BF16, F32
     pipe = OcrPipeline(east_params, crnn_params, device=local_rank, compute_dtype=BF16 if args.dtype == 'bf16' else F32)
 
+    if args.share_gpu:
+        pipe.ctx.set_option('lstm_persistent', 0)
     B, S = args.batch, args.size
     images, maps, _ = synth.make_pages(1234 + 4 + 100 * rank, B, S, S, args.words)
     d_img = torch.from_numpy(images).cuda()
     d_maps = torch.from_numpy(maps).cuda()
 
-    def run(n_steps):
-        # n_steps batches streamed through the pipeline (detection of batch i+1 is enqueued while the host
-        # prepares the crops of batch i); every batch is completed, strings included, before run() returns
-        w = bx = 0
-        for out in pipe.run_batches((d_img, d_maps) for _ in range(n_steps)):
-            w, bx = sum(int(o['valid'].sum()) for o in out), sum(len(o['boxes']) for o in out)
-        return w, bx
+    def run(batch_ids):
+        """Streams the batches named by `batch_ids` through the pipeline (detection of batch i+1 is enqueued while
+        the host prepares the crops of batch i); every batch is complete, strings on the host, when it is yielded.
+        -> [(batch id, {'counts', 'boxes', 'texts'})]"""
+        ids, results = [], []
+
+        def feed():
+            for i in batch_ids:
+                ids.append(i)
+                yield d_img, d_maps
+        for k, out in enumerate(pipe.run_batches(feed())):
+            results.append((ids[k], {
+                'counts': [len(o['boxes']) for o in out],
+                'boxes': np.concatenate([o['boxes'] for o in out]) if out else np.zeros((0, 4), np.float32),
+                'texts': [t for o in out for t, v in zip(o['texts'], o['valid']) if v]}))
+        return results
 
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    words = boxes = 0
     if args.warmup:
-        words, boxes = run(args.warmup)
+        run(range(args.warmup))
+    n_batches = world * args.steps
+    queue = PageQueue(n_batches, grp if dist is not None else None)
     pipe.ctx.profile_enable(True)
     sync()
     t0 = time.perf_counter()
-    words, boxes = run(args.steps)
+    local = run(queue)
     torch.cuda.synchronize()
+    gathered = gather_results(local, n_batches, grp if dist is not None else None, dst=0)     # host gather, rank 0
     elapsed = time.perf_counter() - t0
     stats = pipe.ctx.profile_collect()
     pipe.ctx.profile_enable(False)
     if dist is not None:
         dist.barrier()
-    elapsed = max_over_ranks(elapsed, dist, torch.device('cuda', local_rank))
+    elapsed = max_over_ranks(elapsed, dist, None if args.share_gpu else device)
+    my_steps = max(1, len(local))
 
     if rank == 0:
-        pages = world * args.steps * B
+        pages = n_batches * B
+        words = sum(len(r['texts']) for r in gathered)
+        boxes = sum(sum(r['counts']) for r in gathered)
+        acct = stage_accounting(pipe, d_img, d_maps)
         mfma = [s for s in stats if s['flops'] > 0 and s['name'].startswith(('conv_mfma', 'conv_wino', 'conv_bf16', 'gemm_f32'))]
         dom = max(mfma, key=lambda s: s['total_ms'])
-        achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-        # the Winograd kernel is credited with the flop count of the convolution it computes (2*9*Cin*Cout per output
-        # pixel) but its matrix cores execute 16/36 of that: `executed` is what the MFMA peak actually bounds
+        direct = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+        # a Winograd kernel is credited by the stage timers with the flop count of the convolution it computes
+        # (2*9*Cin*Cout per output pixel); its matrix cores execute 36/144 (F(4x4)) or 16/36 (F(2x2)) of that, and only
+        # the executed flops are bounded by the MFMA peak
         wino_frac = 0.25 if dom['name'].startswith('conv_wino4') else (16.0 / 36.0 if dom['name'].startswith('conv_wino') else 1.0)
-        executed = achieved * wino_frac
+        executed = direct * wino_frac
         peak = BF16_MFMA_PEAK_TFLOPS if dom['name'].startswith('conv_bf16') else F32_MFMA_PEAK_TFLOPS
         gpu_ms = sum(s['total_ms'] for s in stats)
         conv_ms = sum(s['total_ms'] for s in mfma)
         conv_tflops = sum(s['flops'] for s in mfma) / (conv_ms * 1e-3) / 1e12
         line = {
-            'metric': 'end-to-end OCR images/sec (1024x1024 page)', 'value': pages / elapsed, 'unit': 'images/s',
+            'metric': 'end-to-end OCR images/sec (%dx%d page)' % (S, S), 'value': pages / elapsed, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.dtype == 'f32' else 'bf16 operands, f32 accumulate (non-default variant)', 'data': 'synthetic',
-            'config': {'workload': 'configs[3]: full EAST->crop->CRNN pipeline on synthetic %dx%d dense-text pages' % (S, S),
-                       'pages_per_step_per_gpu': B, 'words_per_page': words / B, 'decode_candidates_per_page': None,
+            'config': {'workload': 'configs[%d]: full EAST->crop->CRNN pipeline on synthetic %dx%d dense-text pages, %d-class CTC head'
+                                   % (4 if args.vocab > 1000 else 3, S, S, args.vocab),
+                       'pages_per_step_per_gpu': B, 'words_per_page': words / pages, 'boxes_per_page': boxes / pages,
+                       'decode_candidates_per_page': acct['decode_candidates'] / B,
                        'detector_maps': 'teacher maps of the rendered pages feed decode; the random-weight EAST forward '
-                                        'runs and is timed', 'parallelism': 'image-sharded x%d' % world},
-            'words_per_s': world * args.steps * words / elapsed,
+                                        'runs and is timed',
+                       'parallelism': 'image-sharded x%d, one shared batch queue, boxes + strings gathered on the host of '
+                                      'rank 0 inside the timed region' % world,
+                       'batches_taken_by_rank0': len(local)},
+            **({'rehearsal': '--share-gpu: all ranks on one GPU, not a scaling result'} if args.share_gpu else {}),
+            'words_per_s': words / elapsed,
             'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'launches': dom['launches'],
-                         'avg_ms': dom['total_ms'] / dom['launches'], 'achieved': achieved,
-                         'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'executed_tflops': executed, 'executed_frac': executed / peak,
-                         'algorithm': ('Winograd F(4x4,3x3): `achieved` counts the direct convolution\'s flops, the matrix '
-                                       'cores execute 36/144 of them (`executed`)') if dom['name'].startswith('conv_wino4')
-                         else ('Winograd F(2x2,3x3): `achieved` counts the direct convolution\'s flops, the matrix '
-                               'cores execute 16/36 of them (`executed`)') if dom['name'].startswith('conv_wino')
-                         else 'direct implicit GEMM',
+                         'avg_ms': dom['total_ms'] / dom['launches'], 'achieved': executed,
+                         'peak': peak, 'unit': 'TFLOP/s', 'frac': executed / peak,
+                         'direct_equiv_tflops': direct,
+                         'algorithm': ('Winograd F(4x4,3x3): the matrix cores execute 36/144 of the direct convolution\'s flops; '
+                                       '`achieved` counts the executed ones, `direct_equiv_tflops` the convolution computed')
+                         if dom['name'].startswith('conv_wino4')
+                         else ('Winograd F(2x2,3x3): the matrix cores execute 16/36 of the direct convolution\'s flops; '
+                               '`achieved` counts the executed ones, `direct_equiv_tflops` the convolution computed')
+                         if dom['name'].startswith('conv_wino') else 'direct implicit GEMM',
                          'traffic': pmc_traffic(dom['name']),
                          'algorithmic_bytes': dom['bytes'] / dom['launches'],
-                         'flop_per_launch': dom['flops'] / dom['launches']},
-            'gpu_time': {'kernels_ms_per_step': gpu_ms / args.steps, 'all_mfma_conv_tflops': conv_tflops,
-                         'stages_ms_per_step': {s['name']: round(s['total_ms'] / args.steps, 3) for s in stats}},
+                         'executed_flop_per_launch': dom['flops'] * wino_frac / dom['launches']},
+            'roofline_hbm': hbm_rooflines(stats, acct, args.vocab, my_steps),
+            'gpu_time': {'kernels_ms_per_step': gpu_ms / my_steps, 'all_mfma_conv_tflops_direct_equiv': conv_tflops,
+                         'stages_ms_per_step': {s['name']: round(s['total_ms'] / my_steps, 3) for s in stats}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.vocab == 97:
             line['cpu_baseline'] = cpu_baseline(images, maps, east_params, crnn_params, min(args.cpu_pages, B))
         print(json.dumps(line), flush=True)
     pipe.ctx.close()

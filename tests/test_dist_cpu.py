@@ -52,6 +52,57 @@ def test_two_rank_sharding_and_gather():
         assert slowest == 2.0                                              # MAX over ranks
 
 
+def _queue_worker(rank, world, port, n_items, q):
+    """Dynamic assignment with uneven costs: rank 1 needs 8x as long per page batch as rank 0."""
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from ocr_amd import dist as D
+    grp = D.init_from_env(backend='gloo')
+    queue = D.PageQueue(n_items, grp)
+    grp.dist.barrier()
+    local = []
+    for i in queue:
+        time.sleep(0.16 if rank == 1 else 0.02)
+        local.append((i, {'page': i, 'texts': ['w%d' % i] * (i % 4), 'rank': rank}))
+    full = D.gather_results(local, n_items, grp, dst=0)
+    grp.dist.barrier()
+    q.put((rank, queue.taken, None if full is None else [(f['page'], f['rank']) for f in full]))
+    grp.dist.destroy_process_group()
+
+
+def test_two_rank_dynamic_queue_balances_uneven_costs():
+    world, n_items = 2, 27
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_queue_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, taken0, full), (_, taken1, none) = got
+    assert none is None                                                    # only the destination rank holds the result
+    assert sorted(taken0 + taken1) == list(range(n_items))                 # every batch exactly once
+    assert len(taken0) >= 2 * len(taken1) >= 2                             # the fast rank took most of the work
+    assert [p for p, _ in full] == list(range(n_items))                    # gathered in page order
+    assert [r for _, r in full] == [0 if i in taken0 else 1 for i in range(n_items)]
+
+
+def test_gather_results_rejects_lost_and_duplicate_items():
+    import pytest
+    from ocr_amd import dist as D
+    assert D.gather_results([(1, 'b'), (0, 'a')], 2, None) == ['a', 'b']
+    with pytest.raises(RuntimeError):
+        D.gather_results([(0, 'a')], 2, None)
+    with pytest.raises(RuntimeError):
+        D.gather_results([(0, 'a'), (0, 'b')], 2, None)
+    q = D.PageQueue(3)
+    assert list(q) == [0, 1, 2] and q.take() is None
+
+
 def test_single_process_is_a_no_op():
     from ocr_amd import dist as D
     for k in ('RANK', 'WORLD_SIZE'):
