@@ -69,6 +69,12 @@ int ocrhip_destroy(ocrhip_handle h);
  *   0: a direct implicit GEMM (a float32 fma chain over the taps and channels).
  *   "lstm_persistent": 1 (default) runs the recurrence of a BiLSTM layer as one launch of persistent workgroups
  *   (W_hh resident in LDS, h_t handed over through L2); 0 launches one kernel per time step.  Same arithmetic.
+ *   (hidden sizes other than 256 always take the per-step kernel).  A persistent launch needs the whole GPU: its
+ *   workgroups wait for each other, so launches of one process are chained (one at a time per device), and if another
+ *   process or stream holds compute units for seconds a wait gives up, the kernel leaves, and the error surfaces through
+ *   ocrhip_check_errors / the next ocrhip_crnn_forward* call on the handle (OCRHIP_EHIP, "lstm hand-over timed out").
+ *   "lstm_debug_drop_handover": test hook, 0 (default) | 1: one workgroup of the persistent recurrence withholds its
+ *   first hand-over and waits give up after 4096 spins, which exercises the time-out path above.
  *   "wino4_split": 1 (default) runs the F(4x4,3x3) layers with >= 256 input channels as two kernels (transform the
  *   input tiles once into a workspace, then multiply from it); 0 keeps them fused (every 64-channel workgroup transforms
  *   its tile itself).  Same arithmetic, identical results.
@@ -193,7 +199,8 @@ int ocrhip_crop_resize_pack(ocrhip_handle h, const uint8_t* d_img, int B, int H,
  *   FeatureExtraction.ConvNet.{12,15}.{weight,bias,running_mean,running_var},
  *   SequenceModeling.{0,1}.rnn.{weight_ih_l0,weight_hh_l0,bias_ih_l0,bias_hh_l0}[_reverse],
  *   SequenceModeling.{0,1}.linear.{weight,bias}, Prediction.{weight,bias}
- * The vocabulary size is the row count of Prediction.weight.
+ * The vocabulary size is the row count of Prediction.weight; the LSTM width H (`lstm_size`, crnn_arch.py:485-486;
+ * 256 in the gen-2 EasyOCR models, 512 in gen-1) is read off SequenceModeling.0.rnn.weight_hh_l0 (4H, H), a multiple of 64.
  * ResNet extractor (crnn_arch.py:330-425, `backbone='resnet'`): chosen when FeatureExtraction.ConvNet.conv0_1.weight
  * is present; tensors conv0_{1,2}, bn0_{1,2}, layer{1..4}.{b}.{conv1,bn1,conv2,bn2}, layer{1,2,3}.0.downsample.{0,1},
  * conv{1,2,3}, bn{1,2,3}, conv4_{1,2}, bn4_{1,2} under FeatureExtraction.ConvNet (EasyOCR's ResNet_FeatureExtractor
@@ -232,6 +239,15 @@ int ocrhip_crnn_seq_len(ocrhip_handle h, int wpad);
 int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int* out_w, int n, int compute_dtype,
                                int t_stride, float* d_logits, int* d_tokens, float* d_scores, int* d_lengths,
                                ocrhip_stream stream);
+
+/* Asynchronous failures of earlier calls on the handle.  The persistent BiLSTM kernel cannot return a code when a
+ * hand-over between its workgroups times out; it sets a sticky device word that every ocrhip_crnn_forward* call copies
+ * to the host behind its results.  This call reports it: OCRHIP_EHIP with "lstm hand-over timed out" once, then the
+ * word is re-armed; OCRHIP_OK otherwise.  synchronize != 0 waits for `stream` first (so the outputs of every call
+ * enqueued so far are covered); with 0 the caller has already waited (event / stream synchronisation) for the outputs
+ * it is about to use.  ocrhip_crnn_forward* perform the same check on entry.  The reference has no counterpart: its
+ * Keras LSTM raises synchronously. */
+int ocrhip_check_errors(ocrhip_handle h, ocrhip_stream stream, int synchronize);
 
 /* Debug / test access to an activation of the last ocrhip_crnn_forward call (synchronises).
  *   name: "features" (n,T,256), "seq0", "seq1" (n,T,256) */

@@ -50,6 +50,7 @@ SIGNATURES = {
     'ocrhip_crnn_seq_len': (c_int, [c_void_p, c_int]),
     'ocrhip_crnn_forward_packed': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
+    'ocrhip_check_errors': (c_int, [c_void_p, c_void_p, c_int]),
     'ocrhip_crnn_get_activation': (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64)]),
     'ocrhip_ctc_greedy': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                   c_void_p]),

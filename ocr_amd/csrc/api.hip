@@ -34,6 +34,9 @@ struct Bf16Scope {
 static thread_local int g_lstm_persistent = 1;
 int lstm_persistent() { return g_lstm_persistent; }
 void set_lstm_persistent(int on) { g_lstm_persistent = on; }
+static thread_local int g_lstm_debug_drop = 0;
+int lstm_debug_drop() { return g_lstm_debug_drop; }
+void set_lstm_debug_drop(int on) { g_lstm_debug_drop = on; }
 static thread_local int g_conv3x3_winograd = 2;
 int conv3x3_winograd() { return g_conv3x3_winograd; }
 void set_conv3x3_winograd(int on) { g_conv3x3_winograd = on; }
@@ -247,6 +250,7 @@ using namespace ocrhip;
         ocrhip::set_current_profiler(&(h)->prof);                   \
         ocrhip::set_conv3x3_winograd((h)->conv3x3_winograd);        \
         ocrhip::set_lstm_persistent((h)->lstm_persistent);          \
+        ocrhip::set_lstm_debug_drop((h)->lstm_debug_drop);          \
         ocrhip::set_flat_gemm((h)->flat_gemm);                      \
         ocrhip::set_current_workspace(&(h)->wino_ws);               \
         ocrhip::set_wino4_split((h)->wino4_split);                  \
@@ -301,6 +305,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits, &h->crnn.meta, &h->crnn.lstm_counters})
         b->release();
     h->crnn.ring.release();
+    if (h->crnn.lstm_err_host) (void)hipHostFree(h->crnn.lstm_err_host);
     h->decode_stage.release();
     h->lanms_ws.release();
     h->wino_ws.release();
@@ -547,6 +552,13 @@ int ocrhip_crnn_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n
                 OCR_TRY(prepare_conv_mfma(net.conv[i], wf.data(), bf.data(), cfg[i][2], cfg[i][1], cfg[i][3]));
         }
     }
+    {
+        // hidden units of the BiLSTM layers (`lstm_size`, architectures/crnn_arch.py:485-486): read off the recurrent matrix
+        const ocrhip_tensor_desc* t = W.find("SequenceModeling.0.rnn.weight_hh_l0");
+        OCR_REQUIRE(t && t->data && t->ndim == 2 && t->shape[1] >= 64 && t->shape[1] % 64 == 0 && t->shape[0] == 4 * t->shape[1],
+                    "crnn_load_weights: SequenceModeling.0.rnn.weight_hh_l0 must be (4H, H) with H a multiple of 64");
+        net.hidden = (int)t->shape[1];
+    }
     const int Hd = net.hidden;
     for (int l = 0; l < 2; ++l) {
         const std::string pre = "SequenceModeling." + std::to_string(l);
@@ -649,7 +661,7 @@ static int crnn_features_resnet(CrnnNet& net, const float* x, int n, int Wpad, f
 // VGG: T = Wpad/4 - 1, 256 features.
 static int crnn_features(CrnnNet& net, const float* x, int n, int Wpad, float* feats, hipStream_t s) {
     if (net.backbone) return crnn_features_resnet(net, x, n, Wpad, feats, s);
-    const int Hin = 64, Hd = net.hidden;
+    const int Hin = 64;
     const int T = Wpad / 4 - 1;
     const size_t nW = (size_t)n * Wpad;
     OCR_TRY(net.act[0].reserve(nW * 512 * sizeof(float)));      // (n,32,W/2,32) is the largest
@@ -663,7 +675,7 @@ static int crnn_features(CrnnNet& net, const float* x, int n, int Wpad, float* f
     OCR_TRY(launch_conv_mfma(net.conv[4], Bf, A, n, 8, Wpad / 4, 0, true, nullptr, 0, s));          // (n,8,W/4,256)
     OCR_TRY(launch_conv_mfma(net.conv[5], A, Bf, n, 8, Wpad / 4, 2, true, nullptr, 0, s));          // (n,4,W/4,256)
     OCR_TRY(launch_conv_mfma(net.conv[6], Bf, A, n, 4, Wpad / 4, 0, true, nullptr, 0, s));          // (n,3,T,256)
-    OCR_TRY(launch_mean_rows(A, feats, n, 3, T, Hd, s));
+    OCR_TRY(launch_mean_rows(A, feats, n, 3, T, net.feat_c, s));
     return OCRHIP_OK;
 }
 
@@ -679,7 +691,14 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
     OCR_TRY(net.cbuf.reserve((size_t)2 * n * Hd * sizeof(float)));
     OCR_TRY(net.seq.reserve((size_t)R * 2 * Hd * sizeof(float)));
     OCR_TRY(net.lin.reserve((size_t)2 * R * Hd * sizeof(float)));
-    OCR_TRY(net.lstm_counters.reserve(kLstmCounterCount * sizeof(unsigned)));
+    if (!net.lstm_counters.ptr) {
+        OCR_TRY(net.lstm_counters.reserve((kLstmCounterCount + kLstmErrorWords) * sizeof(unsigned)));
+        OCR_HIP_CHECK(hipMemsetAsync(net.lstm_counters.ptr, 0, (kLstmCounterCount + kLstmErrorWords) * sizeof(unsigned), s));
+    }
+    if (!net.lstm_err_host) {
+        OCR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&net.lstm_err_host), sizeof(unsigned), hipHostMallocDefault));
+        *net.lstm_err_host = 0;
+    }
     const float* layer_in = feats;
     for (int l = 0; l < 2; ++l) {
         float* xw_f = net.xw.as<float>();
@@ -695,7 +714,7 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
             int rc = OCRHIP_ESTATE;
             if (lstm_persistent())
                 rc = launch_lstm_layer(xw_f, xw_b, net.whh[l][0].as<float>(), net.whh[l][1].as<float>(), hb0, net.cbuf.as<float>(),
-                                       net.seq.as<float>(), n, Tmax, d_T, d_row0, d_active, net.lstm_counters.as<unsigned>(), s);
+                                       net.seq.as<float>(), n, Tmax, Hd, d_T, d_row0, d_active, net.lstm_counters.as<unsigned>(), s);
             if (rc != OCRHIP_OK && rc != OCRHIP_ESTATE) return rc;
             int first = 0;
             for (int step = 0; rc == OCRHIP_ESTATE && step < Tmax; ++step) {          // one launch per time step instead
@@ -704,7 +723,7 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
                 const float* hp = (step & 1) ? hb1 : hb0;
                 float* hn = (step & 1) ? hb0 : hb1;
                 OCR_TRY(launch_lstm_step(xw_f, xw_b, net.whh[l][0].as<float>(), net.whh[l][1].as<float>(), hp, hn,
-                                         net.cbuf.as<float>(), net.seq.as<float>(), n, Tmax, step, d_T, d_row0, first, s));
+                                         net.cbuf.as<float>(), net.seq.as<float>(), n, Tmax, step, d_T, d_row0, first, Hd, s));
             }
         }
         float* lin = net.lin.as<float>() + (size_t)l * R * Hd;
@@ -713,7 +732,21 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
         layer_in = lin;
     }
     OCR_TRY(launch_conv_mfma(net.pred, layer_in, logits, 1, 1, (int)R, 0, false, nullptr, 0, s));
+    // the sticky error word of the persistent recurrence travels to the host behind the results
+    OCR_HIP_CHECK(hipMemcpyAsync(net.lstm_err_host, net.lstm_counters.as<unsigned>() + kLstmCounterCount, sizeof(unsigned),
+                                 hipMemcpyDeviceToHost, s));
     return OCRHIP_OK;
+}
+
+// A persistent recurrence of an earlier call on this handle gave up waiting for its partner workgroups: that call's
+// outputs are incomplete.  Reports it once (and re-arms the error word behind the work already on the stream).
+static int crnn_report_timeout(CrnnNet& net, hipStream_t s) {
+    if (!net.lstm_err_host || *net.lstm_err_host == 0) return OCRHIP_OK;
+    *net.lstm_err_host = 0;
+    OCR_HIP_CHECK(hipMemsetAsync(net.lstm_counters.as<unsigned>() + kLstmCounterCount, 0, kLstmErrorWords * sizeof(unsigned), s));
+    set_error("lstm hand-over timed out: a persistent BiLSTM launch did not have the whole GPU (another process or stream held "
+              "compute units); the recogniser outputs of that call are invalid.  Retry, or ocrhip_set_option(h, \"lstm_persistent\", 0)");
+    return OCRHIP_EHIP;
 }
 
 int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, int compute_dtype, float* d_logits,
@@ -725,6 +758,7 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
         return OCRHIP_ESTATE;
     }
     OCR_REQUIRE(d_crops && n > 0 && Wpad >= 8 && Wpad % 4 == 0, "crnn_forward: bad arguments n=%d Wpad=%d", n, Wpad);
+    OCR_TRY(crnn_report_timeout(net, (hipStream_t)stream));
     OCR_REQUIRE(compute_dtype == OCRHIP_F32 || compute_dtype == OCRHIP_BF16, "crnn_forward: compute dtype %d is neither F32 nor BF16", compute_dtype);
     Bf16Scope bf16_scope(compute_dtype);
     OCR_REQUIRE(d_logits || d_tokens, "crnn_forward: ask for logits and/or tokens");
@@ -759,6 +793,7 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
         return OCRHIP_ESTATE;
     }
     OCR_REQUIRE(d_packed && out_w && n > 0, "crnn_forward_packed: bad arguments n=%d", n);
+    OCR_TRY(crnn_report_timeout(net, (hipStream_t)stream));
     OCR_REQUIRE(compute_dtype == OCRHIP_F32 || compute_dtype == OCRHIP_BF16, "crnn_forward_packed: compute dtype %d is neither F32 nor BF16", compute_dtype);
     Bf16Scope bf16_scope(compute_dtype);
     OCR_REQUIRE(d_logits || d_tokens, "crnn_forward_packed: ask for logits and/or tokens");
@@ -821,6 +856,12 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
     return OCRHIP_OK;
 }
 
+int ocrhip_check_errors(ocrhip_handle h, ocrhip_stream stream, int synchronize) {
+    OCR_HANDLE(h);
+    if (synchronize) OCR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return crnn_report_timeout(h->crnn, (hipStream_t)stream);
+}
+
 int ocrhip_crnn_get_activation(ocrhip_handle h, const char* name, float* dst, int64_t dst_capacity, int64_t shape[4]) {
     OCR_HANDLE(h);
     return read_activation(h->crnn.taps, name, dst, dst_capacity, shape);
@@ -843,6 +884,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "lstm_persistent") == 0) {
         OCR_REQUIRE(value == 0 || value == 1, "set_option: lstm_persistent is 0 or 1");
         h->lstm_persistent = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "lstm_debug_drop_handover") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: lstm_debug_drop_handover is 0 or 1");
+        h->lstm_debug_drop = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "wino4_split") == 0) {

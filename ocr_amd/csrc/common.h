@@ -135,6 +135,7 @@ struct CrnnNet {
     ConvLayer pred;          // 256 -> vocab
     DevBuf act[3];
     DevBuf feats, xw, hbuf, cbuf, seq, lin, logits, meta, lstm_counters;
+    unsigned* lstm_err_host = nullptr;   // pinned: copy of the kernel's sticky error word, refreshed after every forward
     PinnedRing ring;
     std::map<std::string, Activation> taps;
 };
@@ -147,6 +148,7 @@ struct ocrhip_ctx {
     ocrhip::CrnnNet crnn;
     ocrhip::DevBuf decode_stage;   // staging of the decode kernel
     ocrhip::DevBuf lanms_ws;       // scratch of the LANMS kernel
+    int lstm_debug_drop = 0;       // test hook: the persistent recurrence withholds one hand-over and times out quickly
     int lstm_persistent = 1;       // recurrence of a BiLSTM layer in one persistent launch (1) or one launch per step (0)
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     int wino4_split = 1;           // F(4x4,3x3) layers with >= 256 input channels: transform once into `wino_ws`, multiply from it (1) or fused (0)
@@ -241,15 +243,19 @@ int launch_resize_rgb_norm(const void* img, bool is_u8, int B, int H, int W, int
 int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
 int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, const float* h_prev,
                      float* h_next, float* c_state, float* out, int n, int T, int step, const int* seq_T,
-                     const int* seq_row0, int first, hipStream_t s);
+                     const int* seq_row0, int first, int H, hipStream_t s);
 
 // rnn_persistent.hip: a whole bidirectional layer in one launch of persistent workgroups (hbuf: 2 parities x 2 directions x n x 256,
-// counters: kLstmCounterCount unsigned ints).  OCRHIP_ESTATE when the device cannot hold the grid at once or a workgroup
-// would need more passes than it has counters (use the per-step kernel).
+// counters: kLstmCounterCount unsigned ints cleared per launch, followed by kLstmErrorWords sticky error words the kernel
+// sets when a hand-over between workgroups times out).  OCRHIP_ESTATE when the hidden size is not 256, the device cannot
+// hold the grid at once or a workgroup would need more passes than it has counters (use the per-step kernel).
 constexpr int kLstmCounterCount = 2 * 16 * 64;
+constexpr int kLstmErrorWords = 16;
 int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, float* hbuf, float* cbuf,
-                      float* out, int n, int T, const int* seq_T, const int* seq_row0, const int* step_active,
+                      float* out, int n, int T, int H, const int* seq_T, const int* seq_row0, const int* step_active,
                       unsigned* counters, hipStream_t s);
+int lstm_debug_drop();               // test hook of the handle in use on this thread: withhold one hand-over (see ocrhip.h)
+void set_lstm_debug_drop(int on);
 int lstm_persistent();               // option of the handle in use on this thread
 void set_lstm_persistent(int on);
 

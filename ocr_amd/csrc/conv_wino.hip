@@ -30,6 +30,8 @@
 // which 16/36 are executed.
 #include <type_traits>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace ocrhip {
@@ -493,8 +495,10 @@ int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H,
                    4.0 * (out_px * L.cin + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout), s);
     const dim3 grid((unsigned)wgs), block(128 * chb);
     static bool lds_opt_in_dev[64] = {};        // more than 64 KB of LDS per workgroup needs an opt-in per kernel and device
+    static std::mutex lds_opt_in_mutex;          // handles of several host threads launch through here
     int dev = 0;
     OCR_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lds_opt_in_lock(lds_opt_in_mutex);
     bool& lds_opt_in = lds_opt_in_dev[dev & 63];
 #define OCR_WINO_FOR_ALL(X) X(0, 2) X(1, 2) X(2, 2) X(0, 4) X(1, 4) X(2, 4)
     if (!lds_opt_in) {

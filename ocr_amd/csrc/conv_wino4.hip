@@ -28,6 +28,8 @@
 // 36/144 are executed.
 #include <type_traits>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace ocrhip {
@@ -490,8 +492,10 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     const int64_t wgs = (int64_t)a.tiles_per_image * a.n_blocks_n * (a.pair ? (B + 1) / 2 : B);
     OCR_REQUIRE(wgs < (1ll << 31), "conv_wino4: too many workgroups");
     static bool lds_opt_in_dev[64] = {};        // more than 64 KB of LDS per workgroup needs an opt-in per kernel and device
+    static std::mutex lds_opt_in_mutex;          // handles of several host threads launch through here
     int dev = 0;
     OCR_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lds_opt_in_lock(lds_opt_in_mutex);
     bool& lds_opt_in = lds_opt_in_dev[dev & 63];
 #define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2)
     if (!lds_opt_in) {

@@ -21,8 +21,6 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kHidden = 256;
-
 __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
                                                         int64_t row_elems, int64_t total) {
     // x: (B,H,W,C) -> y: (B,W,C); row_elems = W*C
@@ -42,22 +40,23 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict_
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 struct LstmArgs {
-    const float* xw[2];      // per direction (n, T, 1024), bias included; column = unit * 4 + gate
-    const float* whh[2];     // per direction (1024, 256)
-    const float* h_prev;     // (2, n, 256)
-    float* h_next;           // (2, n, 256)
-    float* c_state;          // (2, n, 256)
-    float* out;              // (n, T, 512)
+    const float* xw[2];      // per direction (n, T, 4H), bias included; column = unit * 4 + gate
+    const float* whh[2];     // per direction (4H, H)
+    const float* h_prev;     // (2, n, H)
+    float* h_next;           // (2, n, H)
+    float* c_state;          // (2, n, H)
+    float* out;              // (n, T, 2H)
     const int* seq_T;        // ragged mode: time steps of each sequence (non-decreasing), else nullptr
     const int* seq_row0;     // ragged mode: first row of each sequence in the flat (sum T, .) matrices
     int n, T, step, first;   // first = first sequence still active at this step (ragged mode)
+    int H;                   // hidden units, a multiple of 64 (crnn_arch.py:485-486 `lstm_size`)
 };
 
 constexpr int kSeqTile = 64;     // sequences per workgroup
 constexpr int kLds = 64 + 4;     // floats per staged row (64 k values + pad: conflict-free ds_read_b128)
 
-// grid (ceil(active/64), 8, 2), block 256.  Workgroup tile: 64 sequences x 32 hidden units x 4 gates;
-// wave g owns gate g (two 32x32 accumulators, full K = 256).  h_{t-1} and W_hh are staged through LDS in
+// grid (ceil(active/64), H/32, 2), block 256.  Workgroup tile: 64 sequences x 32 hidden units x 4 gates;
+// wave g owns gate g (two 32x32 accumulators, full K = H).  h_{t-1} and W_hh are staged through LDS in
 // K chunks of 64 with fully coalesced 16-byte loads (a row's 256 bytes by 16 consecutive lanes); the next
 // chunk is prefetched into registers during the MFMAs.  The four gates of an element meet in LDS.
 __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int s0 = a.first + blockIdx.x * kSeqTile, u0 = blockIdx.y * 32, dir = blockIdx.z;
-    const int n = a.n;
+    const int n = a.n, kHidden = a.H, kChunks = a.H / 64;
 
     floatx16 acc[2];
 #pragma unroll
@@ -104,8 +103,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
         load_chunk(0);
         store_chunk();
         __syncthreads();
-        for (int kc = 0; kc < 4; ++kc) {
-            if (kc + 1 < 4) load_chunk(kc + 1);
+        for (int kc = 0; kc < kChunks; ++kc) {
+            if (kc + 1 < kChunks) load_chunk(kc + 1);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float4 b4 = *reinterpret_cast<const float4*>(&Bs[(wave * 32 + li) * kLds + q * 8 + lh * 4]);
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
                 }
             }
             __syncthreads();
-            if (kc + 1 < 4) {
+            if (kc + 1 < kChunks) {
                 store_chunk();
                 __syncthreads();
             }
@@ -175,16 +174,18 @@ int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipSt
 
 int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, const float* h_prev,
                      float* h_next, float* c_state, float* out, int n, int T, int step, const int* seq_T,
-                     const int* seq_row0, int first, hipStream_t s) {
+                     const int* seq_row0, int first, int H, hipStream_t s) {
     OCR_REQUIRE(xw_f && xw_b && whh_f && whh_b && h_prev && h_next && c_state && out, "lstm_step: null argument");
     OCR_REQUIRE(n > 0 && T > 0 && step >= 0 && step < T && first >= 0 && first < n,
                 "lstm_step: bad sizes n=%d T=%d step=%d first=%d", n, T, step, first);
     OCR_REQUIRE((seq_T == nullptr) == (seq_row0 == nullptr), "lstm_step: seq_T and seq_row0 go together");
+    OCR_REQUIRE(H >= 64 && H % 64 == 0, "lstm_step: the hidden size must be a multiple of 64 (got %d)", H);
     LstmArgs a;
+    a.H = H;
     a.seq_T = seq_T; a.seq_row0 = seq_row0; a.first = first;
     a.xw[0] = xw_f; a.xw[1] = xw_b; a.whh[0] = whh_f; a.whh[1] = whh_b;
     a.h_prev = h_prev; a.h_next = h_next; a.c_state = c_state; a.out = out; a.n = n; a.T = T; a.step = step;
-    dim3 grid((n - first + kSeqTile - 1) / kSeqTile, kHidden / 32, 2);
+    dim3 grid((n - first + kSeqTile - 1) / kSeqTile, H / 32, 2);
     hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;

@@ -21,12 +21,16 @@
 // accesses and one atomic counter per (direction, g, pass) says when a pass of a step is complete.  With two or more
 // passes the hand-over costs no waiting: the partners published pass p of step t-1 a pass ago.
 // Nothing else synchronises; a group whose sequences are all finished leaves.  The grid never exceeds what the device
-// holds at once (occupancy x CUs, checked by the launcher: the hand-over needs every workgroup resident); the spin
-// on the counter is bounded so that a lost partner can never hang the device: the wait gives up after ~1 s and the
-// workgroup runs on with whatever it finds.
+// holds at once (occupancy x CUs, checked by the launcher: the hand-over needs every workgroup resident, and launches
+// of this kernel on one device are chained through an event so that two of them never share the device); the spin on
+// the counter is bounded so that a lost partner can never hang the device: a wait that gives up sets a sticky error
+// word and the workgroup LEAVES (its partners see the word within 256 spins and leave too).  The layer's output is
+// then incomplete; the host reads the error word with the results and fails the call (ocrhip_check_errors).
 //
 // Bound: latency of the per-step hand-over for short batches, f32 MFMA rate for large ones
 // (2 * 2 * n_active * 1024 * 256 flop per step).
+#include <mutex>
+
 #include "common.h"
 
 namespace ocrhip {
@@ -53,7 +57,10 @@ struct LayerArgs {
     const int* seq_row0;     // first row of each sequence in the flat matrices; nullptr: s * T
     const int* step_active;  // sequences with more than t steps, per step t; nullptr: n
     unsigned* counters;      // (2 directions x G, kMaxPass), zero at launch
+    unsigned* error;         // sticky: set to 1 by a workgroup whose wait for its partners timed out
     int n, T, G;
+    int spin_cap;            // spins of a wait before it gives up
+    int debug_drop;          // test hook: unit block 7 of (direction 0, group 0) never publishes step 0
 };
 
 // The cell update of 14 elements per lane sits on the critical path of every step, on a SIMD that runs one wave: what
@@ -154,6 +161,7 @@ __device__ __forceinline__ void gemm_pass(const float* __restrict__ hprev, const
 template <bool RAGGED>
 __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int bail;             // a wait of this workgroup timed out (or a partner's did): leave
     float* Ws = lds;                 // [row R = wave*32 + gate*8 + unit8][64 slots of 16 bytes, slot c stored at c ^ (R & 15)]
     float* As = lds + kWFloats;      // [2 buffers][row][kAS]
 
@@ -187,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
             *reinterpret_cast<float4*>(&Ws[(R * 64 + (c ^ (R & 15))) * 4]) = v;
         }
     }
+    if (tid == 0) bail = 0;
     __syncthreads();
 
     // local rows: row j of pass p is the sequence of descending-length rank d = (p * kRows + j) * G + g
@@ -281,12 +290,19 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
                 if (tid == 0) {
                     const unsigned want = 8u * (unsigned)t;
                     int spins = 0;
-                    while (__hip_atomic_load(counters + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1 << 22)) {
+                    while (__hip_atomic_load(counters + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
+                        const bool partner_gave_up = (spins & 255) == 0 && __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        if (spins >= a.spin_cap || partner_gave_up) {
+                            __hip_atomic_fetch_or(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            bail = 1;
+                            break;
+                        }
                     }
                 }
                 __syncthreads();
+                if (bail) return;                 // uniform: every thread reads the same LDS word after the barrier
                 int64_t hoff[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -351,7 +367,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
             // publish pass p of h_t, then write what only this workgroup reads again
             __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): this thread's h stores have reached the coherence point
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(counters + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool dropped = a.debug_drop && sg == 0 && ub == 7 && t == 0;
+            if (tid == 0 && !dropped) __hip_atomic_fetch_add(counters + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flush_cells();
         }
     }
@@ -360,19 +377,32 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
 }  // namespace
 
 // One bidirectional LSTM layer over n sequences in one launch of persistent workgroups.  `counters` must hold
-// kLstmCounterCount unsigned ints (they are cleared here).  Returns OCRHIP_ESTATE when the device cannot hold the grid at once; the caller then
+// kLstmCounterCount + kLstmErrorWords unsigned ints (the counters are cleared here, the error words are sticky).
+// Returns OCRHIP_ESTATE when the hidden size is not 256 or the device cannot hold the grid at once; the caller then
 // uses the per-step kernel.
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_mutex;                         // guards the per-device state below and orders persistent launches
+int g_max_groups[kMaxDevices];              // sequence groups such that 16 * G workgroups are resident at once (0: not probed, -1: none)
+hipEvent_t g_last_launch[kMaxDevices];      // recorded behind the last persistent launch on the device
+}  // namespace
+
 int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, float* hbuf, float* cbuf,
-                      float* out, int n, int T, const int* seq_T, const int* seq_row0, const int* step_active,
+                      float* out, int n, int T, int H, const int* seq_T, const int* seq_row0, const int* step_active,
                       unsigned* counters, hipStream_t s) {
     OCR_REQUIRE(xw_f && xw_b && whh_f && whh_b && hbuf && cbuf && out && counters, "lstm_layer: null argument");
     OCR_REQUIRE(n > 0 && T > 0, "lstm_layer: bad sizes n=%d T=%d", n, T);
     OCR_REQUIRE((seq_T == nullptr) == (seq_row0 == nullptr) && (seq_T == nullptr) == (step_active == nullptr),
                 "lstm_layer: seq_T, seq_row0 and step_active go together");
-    static int max_groups[64] = {};            // per device: sequence groups such that 16 * G workgroups are resident at once
+    if (H != kH) {
+        set_error("lstm_layer: the persistent kernel holds W_hh slices of %d hidden units in LDS, the model has %d (the per-step kernel runs instead)", kH, H);
+        return OCRHIP_ESTATE;
+    }
     int dev = 0;
     OCR_HIP_CHECK(hipGetDevice(&dev));
-    int& mg = max_groups[dev & 63];
+    OCR_REQUIRE(dev >= 0 && dev < kMaxDevices, "lstm_layer: device index %d", dev);
+    std::lock_guard<std::mutex> lock(g_mutex);
+    int& mg = g_max_groups[dev];
     if (mg == 0) {
         OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
@@ -390,13 +420,21 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
     LayerArgs a;
     a.xw[0] = xw_f; a.xw[1] = xw_b; a.whh[0] = whh_f; a.whh[1] = whh_b;
     a.hbuf = hbuf; a.cbuf = cbuf; a.out = out; a.seq_T = seq_T; a.seq_row0 = seq_row0; a.step_active = step_active;
-    a.counters = counters; a.n = n; a.T = T;
+    a.counters = counters; a.error = counters + kLstmCounterCount; a.n = n; a.T = T;
+    a.debug_drop = lstm_debug_drop();
+    a.spin_cap = a.debug_drop ? (1 << 12) : (1 << 22);       // ~1 us per spin: seconds before a real wait gives up
     a.G = std::max(1, std::min(mg, (n + 15) / 16));          // no more groups than 16-row tiles of work
     if (((n + a.G - 1) / a.G + kRows - 1) / kRows > kMaxPass) {
         set_error("lstm_layer: more passes per workgroup than counters (n=%d)", n);
         return OCRHIP_ESTATE;
     }
     static_assert(kLstmCounterCount == 2 * 16 * kMaxPass, "counter buffer size");
+    // Two persistent grids on one device would each get part of the CUs and wait for workgroups that cannot start:
+    // a launch waits for the persistent launch before it, whichever stream or handle of this process made it.
+    if (g_last_launch[dev])
+        OCR_HIP_CHECK(hipStreamWaitEvent(s, g_last_launch[dev], 0));
+    else
+        OCR_HIP_CHECK(hipEventCreateWithFlags(&g_last_launch[dev], hipEventDisableTiming));
     OCR_HIP_CHECK(hipMemsetAsync(counters, 0, kLstmCounterCount * sizeof(unsigned), s));
     // a plain launch: the grid is sized to what the device holds at once (checked above), which is all the hand-over
     // needs; the cooperative-launch entry point, which performs the same check, crashes the profiler at process exit
@@ -405,6 +443,7 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
     else
         hipLaunchKernelGGL(lstm_layer_kernel<false>, dim3(16 * a.G), dim3(256), kLdsBytes, s, a);
     OCR_HIP_CHECK(hipGetLastError());
+    OCR_HIP_CHECK(hipEventRecord(g_last_launch[dev], s));
     return OCRHIP_OK;
 }
 

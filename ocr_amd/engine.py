@@ -253,6 +253,11 @@ class HipContext:
                                                   _ptr(lengths), _stream()))
         return {'tokens': tokens, 'scores': scores, 'lengths': lengths, 'logits': logits}
 
+    def check_errors(self, synchronize=True):
+        """Raises OcrHipError when a persistent BiLSTM launch of an earlier call timed out (its outputs are invalid).
+        synchronize=False: the caller has already waited for the outputs it is about to use."""
+        check(self.lib.ocrhip_check_errors(self._h, _stream(), 1 if synchronize else 0))
+
     def crnn_activation(self, name):
         return self._activation(self.lib.ocrhip_crnn_get_activation, name)
 

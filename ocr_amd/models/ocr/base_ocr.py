@@ -15,7 +15,7 @@ import torch
 from .. import register_model
 from ..detection.east import get_image_data, load_image
 from ...runtimes import HIPRuntime
-from ...utils.image_sizes import plan_crops
+from ...utils.image_sizes import plan_crops, quantise_u8
 from ...utils.saving import FunctionCallback, JSONSaver, QueueCallback, apply_callbacks, load_json
 from ...utils.text import CharTokenizer, ENGLISH_G2_CHARACTERS
 
@@ -105,8 +105,7 @@ class BaseOCR:
             method = 'beam_search'
         if method not in ('greedy', 'beam_search'):
             raise ValueError('Unknown CTC decoding method : {}'.format(method))
-        if image.dtype != np.uint8:
-            image = np.clip(np.asarray(image) * 255, 0, 255).astype(np.uint8) if image.dtype.kind == 'f' else image.astype(np.uint8)
+        image = quantise_u8(image)          # float input (u / 255) is rounded back to 8 bits
         if image.shape[2] == 1:
             image = np.repeat(image, 3, axis=2)
         d_img = torch.from_numpy(np.ascontiguousarray(image)).to(self.ctx.device)[None]
@@ -121,11 +120,13 @@ class BaseOCR:
         res = self.ctx.crnn_forward_packed(sorted_packed, widths, want_logits=(method == 'beam_search'))
         if method == 'greedy':
             toks, sc = res['tokens'].cpu().numpy(), res['scores'].cpu().numpy()
+            self.ctx.check_errors(synchronize=False)
         else:
             from ...utils.ctc_beam import ctc_beam_search
             T = self.ctx.seq_len(widths)
             row0 = np.concatenate([[0], np.cumsum(T)])
             flat = res['logits'].cpu().numpy()
+            self.ctx.check_errors(synchronize=False)
             padded = np.zeros((n, int(T.max()), flat.shape[1]), np.float32)      # pad_batch(pad_value=0.)
             for k in range(n):
                 padded[k, :T[k]] = flat[row0[k]:row0[k + 1]]

@@ -122,6 +122,7 @@ class OcrPipeline:
         if st['n'] == 0:
             return out
         st['tokens_ready'].synchronize()
+        self.ctx.check_errors(synchronize=False)        # a timed-out recurrence fails the batch instead of returning garbage
         tokens, scores = st['h_tokens'].numpy(), st['h_scores'].numpy()
         box_img, box_idx = st['box_img'], st['box_idx']
         decode = self.tokenizer.decode

@@ -85,3 +85,15 @@ def plan_crops(boxes_rel, image_h, image_w, height=64, multiple=64):
     rects = np.stack([x0, y0, x1, y1], axis=1)[keep].astype(np.int32)
     return {'rects': rects.reshape(-1, 4), 'inter': np.stack([ih, iw], axis=1)[keep].astype(np.int32).reshape(-1, 2),
             'out_w': w_out[keep].astype(np.int32), 'index': keep.astype(np.int64)}
+
+
+def quantise_u8(image):
+    """Pixels for the GPU path, which reads uint8 pages.  Float images hold u/255 (what the reference's loader
+    produces, utils/image/image_io.py:126-128): they are ROUNDED to the nearest integer (u/255*255 falls just below u
+    for a number of values, so truncation would darken those pixels by one); other integer types are cast."""
+    image = np.asarray(image)
+    if image.dtype == np.uint8:
+        return image
+    if image.dtype.kind == 'f':
+        return np.clip(np.rint(image.astype(np.float32) * np.float32(255)), 0, 255).astype(np.uint8)
+    return image.astype(np.uint8)

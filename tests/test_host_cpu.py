@@ -88,3 +88,13 @@ def test_registries_raise_like_the_reference():
     assert called['ok']
     polys = np.array([[[0.1, 0.2], [0.5, 0.2], [0.5, 0.4], [0.1, 0.4]]], np.float32)
     np.testing.assert_allclose(convert_box_format(polys, source='poly', target='xyxy'), [[0.1, 0.2, 0.5, 0.4]], atol=1e-7)
+
+
+def test_float_images_round_trip_to_uint8():
+    """uint8 -> float32 / 255 (the reference's loader) -> the GPU path's uint8 is the identity for all 256 values."""
+    from ocr_amd.utils.image_sizes import quantise_u8
+    u = np.arange(256, dtype=np.uint8).reshape(16, 16, 1)
+    np.testing.assert_array_equal(quantise_u8(u.astype(np.float32) / np.float32(255)), u)
+    np.testing.assert_array_equal(quantise_u8((u / 255.0).astype(np.float64)), u)
+    assert quantise_u8(u) is u
+    np.testing.assert_array_equal(quantise_u8(np.array([[-0.1, 1.2]], np.float32)), [[0, 255]])
