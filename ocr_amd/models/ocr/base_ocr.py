@@ -242,4 +242,11 @@ class BaseOCR:
 
 class CRNN(BaseOCR):
     """models/ocr/crnn.py: EasyOCR recogniser (64 x W x 1 input, 'easyocr' normalisation, char vocabulary
-    ['<blank>'] + characters)."""
+    ['<blank>'] + characters).  `pretrained` names one of the EasyOCR recognisers the reference lists
+    (architectures/crnn_arch.py:45-203, e.g. 'zh_sim_g2', 'latin_g2'): its character table becomes the vocabulary."""
+
+    def __init__(self, lang='multi', weights=None, *, pretrained=None, **kwargs):
+        if pretrained is not None and 'characters' not in kwargs:
+            from ...utils.text import get_characters
+            kwargs['characters'] = get_characters(pretrained)
+        super().__init__(lang, weights, **kwargs)

@@ -6,6 +6,31 @@ ENGLISH_G2_CHARACTERS = ('0123456789!"#$%&\'()*+,-./:;<=>?@[\\]^_`{|}~ €'
                          'ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz')
 
 
+_CHARSETS = None
+
+
+def easyocr_models():
+    """name -> dict(generation, filename, script, characters) of every EasyOCR recogniser the reference lists
+    (architectures/crnn_arch.py:45-203): `characters` is the class order of the checkpoint after the blank.
+    Read from the data file charsets.json next to this module (made by tools/make_charsets.py)."""
+    global _CHARSETS
+    if _CHARSETS is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'charsets.json'), encoding='utf-8') as fh:
+            _CHARSETS = json.load(fh)
+    return _CHARSETS
+
+
+def get_characters(model):
+    """Characters of an EasyOCR recogniser by name ('english_g2', 'zh_sim_g2', ...): ValueError when unknown
+    (architectures/crnn_arch.py:785-793)."""
+    table = easyocr_models()
+    if model not in table:
+        raise ValueError('No model found for {} ; known : {}'.format(model, tuple(sorted(table))))
+    return table[model]['characters']
+
+
 class CharTokenizer:
     """vocab = ['<blank>'] + list(characters); ids assigned with `dict.setdefault`, so a repeated
     character keeps its first id and the ids after it shift down (the reference's behaviour)."""

@@ -77,18 +77,25 @@ class CharTokenizer:
         return [self.decode(t) for t in tokens], scores
 
 
+def top2(logits):
+    """(T,V) logits -> (classes (T,2) int, logits (T,2) float32 of the two largest per step (first maximum first),
+    largest magnitude): all a tie check needs."""
+    logits = np.asarray(logits, dtype=np.float32)
+    order = np.argsort(-logits, axis=1, kind='stable')[:, :2]
+    return order, np.take_along_axis(logits, order, axis=1), np.abs(logits).max()
+
+
 def tie_flips(ref_logits, got_text, tokenizer, rel_tol=1e-4, max_ties=14):
-    """Is `got_text` a greedy decoding of `ref_logits` (T,V) apart from argmax ties?
+    """Is `got_text` a greedy decoding of `ref_logits` apart from argmax ties?  `ref_logits`: (T,V) logits, or the
+    `top2(logits)` triple.
 
     A step is a tie when the two largest logits of the step differ by less than `rel_tol` times the
     largest magnitude in `ref_logits` (the tolerance the network outputs are held to).  Returns the
     smallest number of tie steps at which the runner-up has to be taken to produce `got_text`
     (0 = the plain greedy decoding), or None when no choice at the tie steps produces it.
     """
-    ref_logits = np.asarray(ref_logits, dtype=np.float32)
-    order = np.argsort(-ref_logits, axis=1, kind='stable')[:, :2]
-    top = np.take_along_axis(ref_logits, order, axis=1)
-    tol = np.float32(rel_tol) * np.abs(ref_logits).max()
+    order, top, absmax = ref_logits if isinstance(ref_logits, tuple) else top2(ref_logits)
+    tol = np.float32(rel_tol) * np.float32(absmax)
     ties = np.nonzero((top[:, 0] - top[:, 1]) < tol)[0]
     if len(ties) > max_ties:
         ties = ties[np.argsort((top[:, 0] - top[:, 1])[ties])[:max_ties]]
@@ -114,7 +121,7 @@ def tie_flips(ref_logits, got_text, tokenizer, rel_tol=1e-4, max_ties=14):
 
 def assert_texts_match_or_tie(got_texts, ref_texts, ref_logits, tokenizer, rel_tol=1e-4):
     """Every string equals the oracle's, or differs from it only through argmax ties of the oracle's own
-    logits (`tie_flips`).  `ref_logits[k]` are the (T_k,V) logits the oracle decoded string k from.
+    logits (`tie_flips`).  `ref_logits[k]` are the (T_k,V) logits the oracle decoded string k from (or their `top2`).
     Returns the number of strings that needed a tie flip."""
     assert len(got_texts) == len(ref_texts), (len(got_texts), len(ref_texts))
     flipped = 0

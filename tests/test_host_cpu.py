@@ -98,3 +98,23 @@ def test_float_images_round_trip_to_uint8():
     np.testing.assert_array_equal(quantise_u8((u / 255.0).astype(np.float64)), u)
     assert quantise_u8(u) is u
     np.testing.assert_array_equal(quantise_u8(np.array([[-0.1, 1.2]], np.float32)), [[0, 255]])
+
+
+def test_easyocr_character_tables():
+    """Vocabulary sizes of the EasyOCR tables the reference lists (crnn_arch.py:45-203), blank included, after the
+    reference tokenizer's `setdefault` de-duplication (tokenizer.py:189-219)."""
+    import pytest
+    from ocr_amd.utils.text import CharTokenizer, ENGLISH_G2_CHARACTERS, easyocr_models, get_characters
+    sizes = {name: CharTokenizer(info['characters']).vocab_size for name, info in easyocr_models().items()}
+    assert sizes['english_g2'] == 97 and sizes['latin_g2'] == 352 and sizes['zh_sim_g2'] == 6719
+    assert sizes['zh_sim_g1'] == 6710 and sizes['zh_tra_g1'] == 5381 and sizes['japanese_g1'] == 3111
+    assert sizes['japanese_g2'] == 2215 and sizes['korean_g1'] == 1568 and sizes['korean_g2'] == 1009
+    # two tables repeat characters: ids after a repeat shift down, the head is smaller than the table
+    assert len(get_characters('devanagari_g1')) == 187 and sizes['devanagari_g1'] == 183
+    assert len(get_characters('arabic_g1')) == 184 and sizes['arabic_g1'] == 183
+    assert get_characters('english_g2') == ENGLISH_G2_CHARACTERS
+    tok = CharTokenizer(get_characters('zh_sim_g2'))
+    ids = [tok._symbol_to_id[c] for c in '中文OCR']
+    assert tok.decode(ids + [0, 0, 5]) == '中文OCR'
+    with pytest.raises(ValueError):
+        get_characters('klingon_g9')
