@@ -57,6 +57,8 @@ def parse():
                     help="f32 = the reference's precision (the headline); bf16 = bfloat16 operands, float32 accumulation")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-pages', type=int, default=4)
+    ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE',
+                    help='library option for ocrhip_set_option (equivalent algorithms, e.g. fuse_ctc=0, lstm_persistent=0)')
     ap.add_argument('--share-gpu', action='store_true',
                     help='rehearsal of the N-rank path on a box with fewer GPUs: rank r uses GPU r %% visible, gloo instead of '
                          'RCCL for the two bracket collectives (RCCL refuses two ranks on one device), per-step LSTM kernel '
@@ -191,6 +193,9 @@ def main():
 
     if args.share_gpu:
         pipe.ctx.set_option('lstm_persistent', 0)
+    for kv in args.set:
+        name, value = kv.split('=')
+        pipe.ctx.set_option(name, int(value))
     B, S = args.batch, args.size
     images, maps, _ = synth.make_pages(1234 + 4 + 100 * rank, B, S, S, args.words)
     d_img = torch.from_numpy(images).cuda()

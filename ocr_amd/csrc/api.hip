@@ -46,6 +46,7 @@ void set_current_workspace(DevBuf* ws) { g_workspace = ws; }
 static thread_local int g_wino4_split = 1;
 int wino4_split() { return g_wino4_split; }
 void set_wino4_split(int on) { g_wino4_split = on; }
+static thread_local int g_fuse_ctc = 1;
 static thread_local int g_flat_gemm = 1;
 int flat_gemm() { return g_flat_gemm; }
 void set_flat_gemm(int on) { g_flat_gemm = on; }
@@ -252,6 +253,7 @@ using namespace ocrhip;
         ocrhip::set_lstm_persistent((h)->lstm_persistent);          \
         ocrhip::set_lstm_debug_drop((h)->lstm_debug_drop);          \
         ocrhip::set_flat_gemm((h)->flat_gemm);                      \
+        ocrhip::g_fuse_ctc = (h)->fuse_ctc;                         \
         ocrhip::set_current_workspace(&(h)->wino_ws);               \
         ocrhip::set_wino4_split((h)->wino4_split);                  \
     } while (0)
@@ -302,7 +304,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     }
     free_layer(h->crnn.pred);
     for (auto& b : h->crnn.act) b.release();
-    for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits, &h->crnn.meta, &h->crnn.lstm_counters})
+    for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits, &h->crnn.meta, &h->crnn.lstm_counters, &h->crnn.pmax, &h->crnn.pidx})
         b->release();
     h->crnn.ring.release();
     if (h->crnn.lstm_err_host) (void)hipHostFree(h->crnn.lstm_err_host);
@@ -731,11 +733,25 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
         record(net.taps, l == 0 ? "seq0" : "seq1", lin, 1, R, Hd, 1);
         layer_in = lin;
     }
-    OCR_TRY(launch_conv_mfma(net.pred, layer_in, logits, 1, 1, (int)R, 0, false, nullptr, 0, s));
+    if (logits) {
+        OCR_TRY(launch_conv_mfma(net.pred, layer_in, logits, 1, 1, (int)R, 0, false, nullptr, 0, s));
+    } else {
+        // greedy decoding only: the class layer leaves one (maximum, class) pair per row and block of 128 classes
+        const size_t pairs = (size_t)R * gemm_f32_column_blocks(net.pred);
+        OCR_TRY(net.pmax.reserve(pairs * sizeof(float)));
+        OCR_TRY(net.pidx.reserve(pairs * sizeof(int)));
+        OCR_TRY(launch_gemm_f32_argmax(net.pred, layer_in, R, net.pmax.as<float>(), net.pidx.as<int>(), s));
+    }
     // the sticky error word of the persistent recurrence travels to the host behind the results
     OCR_HIP_CHECK(hipMemcpyAsync(net.lstm_err_host, net.lstm_counters.as<unsigned>() + kLstmCounterCount, sizeof(unsigned),
                                  hipMemcpyDeviceToHost, s));
     return OCRHIP_OK;
+}
+
+// Tokens without a logits request: the class layer can hand per-block maxima to the CTC kernel when it runs on the flat
+// float32 GEMM (the bfloat16 variant and flat_gemm = 0 go through the convolution kernels, which write logits).
+static bool crnn_can_fuse_ctc(const CrnnNet& net) {
+    return g_fuse_ctc && flat_gemm() && !compute_bf16() && net.pred.w_gemm.ptr != nullptr;
 }
 
 // A persistent recurrence of an earlier call on this handle gave up waiting for its partner workgroups: that call's
@@ -774,12 +790,17 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
     OCR_TRY(crnn_features(net, reinterpret_cast<const float*>(d_crops), n, Wpad, feats, s));
     record(net.taps, "features", feats, n, T, Fc, 1);
     float* logits = d_logits;
-    if (!logits) {
+    const bool fused = !logits && crnn_can_fuse_ctc(net);
+    if (!logits && !fused) {
         OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));
         logits = net.logits.as<float>();
     }
     OCR_TRY(crnn_sequence(net, feats, n, R, T, nullptr, nullptr, nullptr, nullptr, logits, s));
-    if (d_tokens) OCR_TRY(launch_ctc_greedy(logits, n, T, net.vocab, net.vocab, nullptr, nullptr, 0, d_tokens, d_scores, s));
+    if (fused)
+        OCR_TRY(launch_ctc_greedy_partial(net.pmax.as<float>(), net.pidx.as<int>(), gemm_f32_column_blocks(net.pred), n, T, nullptr,
+                                          nullptr, 0, d_tokens, d_scores, s));
+    else if (d_tokens)
+        OCR_TRY(launch_ctc_greedy(logits, n, T, net.vocab, net.vocab, nullptr, nullptr, 0, d_tokens, d_scores, s));
     return OCRHIP_OK;
 }
 
@@ -846,12 +867,16 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
     }
     record(net.taps, "features", feats, 1, R, Fc, 1);
     float* logits = d_logits;
-    if (!logits) {
+    const bool fused = !logits && crnn_can_fuse_ctc(net);
+    if (!logits && !fused) {
         OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));
         logits = net.logits.as<float>();
     }
     OCR_TRY(crnn_sequence(net, feats, n, R, Tmax, meta.data(), d_T, d_row0, d_active, logits, s));
-    if (d_tokens)
+    if (fused)
+        OCR_TRY(launch_ctc_greedy_partial(net.pmax.as<float>(), net.pidx.as<int>(), gemm_f32_column_blocks(net.pred), n, t_stride, d_T,
+                                          d_row0, 0, d_tokens, d_scores, s));
+    else if (d_tokens)
         OCR_TRY(launch_ctc_greedy(logits, n, t_stride, net.vocab, net.vocab, d_T, d_row0, 0, d_tokens, d_scores, s));
     return OCRHIP_OK;
 }
@@ -894,6 +919,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "wino4_split") == 0) {
         OCR_REQUIRE(value == 0 || value == 1, "set_option: wino4_split is 0 or 1");
         h->wino4_split = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "fuse_ctc") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: fuse_ctc is 0 or 1");
+        h->fuse_ctc = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "flat_gemm") == 0) {

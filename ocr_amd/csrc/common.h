@@ -135,6 +135,7 @@ struct CrnnNet {
     ConvLayer pred;          // 256 -> vocab
     DevBuf act[3];
     DevBuf feats, xw, hbuf, cbuf, seq, lin, logits, meta, lstm_counters;
+    DevBuf pmax, pidx;       // greedy decoding without logits: per row and block of 128 classes the maximum and its class
     unsigned* lstm_err_host = nullptr;   // pinned: copy of the kernel's sticky error word, refreshed after every forward
     PinnedRing ring;
     std::map<std::string, Activation> taps;
@@ -153,6 +154,7 @@ struct ocrhip_ctx {
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     int wino4_split = 1;           // F(4x4,3x3) layers with >= 256 input channels: transform once into `wino_ws`, multiply from it (1) or fused (0)
     ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
+    int fuse_ctc = 1;              // tokens without a logits request: class layer reduced to per-block maxima in its epilogue (1) or logits written and re-read (0)
     int flat_gemm = 1;             // 1x1 / 2x2 layers on the 256 x 128 flat GEMM (1) or on the implicit-GEMM convolution kernel (0)
     ocrhip::Profiler prof;
 };
@@ -200,6 +202,9 @@ void set_conv3x3_winograd(int on);
 // handle's "flat_gemm" option is on (the default) and the layer has neither pooling, upsampling nor a residual.
 int prepare_gemm_f32(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);
 int launch_gemm_f32(const ConvLayer& L, const float* x, float* y, int B, int H, int W, bool relu, hipStream_t s);
+// Dense(vocab) in front of greedy CTC: per row and block of 128 columns the largest value and its column, no logits
+int gemm_f32_column_blocks(const ConvLayer& L);
+int launch_gemm_f32_argmax(const ConvLayer& L, const float* x, int64_t M, float* pmax, int* pidx, hipStream_t s);
 int flat_gemm();                     // option of the handle in use on this thread
 void set_flat_gemm(int on);
 
@@ -264,5 +269,8 @@ void set_lstm_persistent(int on);
 // stride of the token rows.
 int launch_ctc_greedy(const float* logits, int B, int T, int V, int ld_v, const int* lengths, const int* row0, int blank,
                       int* tokens, float* scores, hipStream_t s);
+// the same decoding from the (maximum, column) pairs per block of 128 columns that launch_gemm_f32_argmax writes
+int launch_ctc_greedy_partial(const float* pmax, const int* pidx, int n_blocks, int B, int T, const int* lengths,
+                              const int* row0, int blank, int* tokens, float* scores, hipStream_t s);
 
 }  // namespace ocrhip

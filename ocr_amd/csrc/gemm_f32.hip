@@ -15,6 +15,11 @@
 // is reused by 4 MFMAs and a B operand by 2), K runs in chunks of 16 through a double-buffered LDS image (one barrier
 // per chunk, the global loads of chunk k + 1 issued before the MFMAs of chunk k), and two workgroups share a CU.
 //
+// ARGMAX variant (the class layer Dense(vocab) in front of greedy CTC decoding, architectures/crnn_arch.py:517-519 +
+// utils/text/ctc_decoder.py:28-32): instead of the 256 x 128 output tile the epilogue writes, per row, the largest
+// value of the tile and its column (the first column among equal values) - the logits never reach memory.  The CTC
+// kernel finishes the argmax over the column blocks.  Same values (acc + bias), so the same tokens and scores.
+//
 // Roofline: MFMA bound (2 M N K flop against 64 flop/clk/SIMD).
 #include <type_traits>
 
@@ -34,6 +39,8 @@ struct GemmArgs {
     const float* w;          // slabs [n block][k chunk][q][h][128 columns][4]: k = chunk * 16 + 8 q + 4 h + t
     const float* bias;       // n_pad floats
     float* y;                // (M, N)
+    float* pmax;             // ARGMAX: (M, n_blocks) largest value of the row within the column block ...
+    int* pidx;               //         ... and its column
     int64_t M;
     int N, K, relu;
     int n_blocks;
@@ -42,6 +49,7 @@ struct GemmArgs {
     int seg_len, seg_stride;
 };
 
+template <bool ARGMAX>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][kAFloats];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBFloats];
@@ -168,6 +176,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
             }
         }
     };
+    if (ARGMAX) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t mrow = m0 + wave * 64 + r * 32 + 4 * lh;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float best = -INFINITY;
+                int best_i = 0x7fffffff;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {                       // ascending columns: a later equal value does not win
+                    const int co = nb * kBN + nt * 32 + li;
+                    const float o = acc[r][nt][v] + biasv[nt];
+                    if (co < a.N && (o > best || best_i == 0x7fffffff)) { best = o; best_i = co; }
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {               // the 32 lanes that hold the row
+                    const float ob = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(best_i, off, 64);
+                    if (oi != 0x7fffffff && (best_i == 0x7fffffff || ob > best || (ob == best && oi < best_i))) { best = ob; best_i = oi; }
+                }
+                const int64_t m = mrow + (v & 3) + 8 * (v >> 2);
+                if (li == 0 && m < a.M) {
+                    a.pmax[m * a.n_blocks + nb] = best;
+                    a.pidx[m * a.n_blocks + nb] = best_i;
+                }
+            }
+        }
+        return;
+    }
     if (full)
         write_out(std::false_type{});
     else
@@ -205,7 +242,7 @@ int launch_gemm_f32(const ConvLayer& L, const float* x, float* y, int B, int H, 
     OCR_REQUIRE(L.w_gemm.ptr && (L.ks == 1 || L.ks == 2), "gemm_f32: layer not prepared");
     OCR_REQUIRE(x && y && B > 0 && H >= L.ks && W >= L.ks, "gemm_f32: bad arguments B=%d H=%d W=%d", B, H, W);
     GemmArgs a;
-    a.x = x; a.w = L.w_gemm.as<float>(); a.bias = L.bias_gemm.as<float>(); a.y = y;
+    a.x = x; a.w = L.w_gemm.as<float>(); a.bias = L.bias_gemm.as<float>(); a.y = y; a.pmax = nullptr; a.pidx = nullptr;
     a.N = L.cout; a.K = L.ks * L.ks * L.cin; a.relu = relu ? 1 : 0;
     a.n_blocks = (L.cout + kBN - 1) / kBN;
     a.H = H; a.W = W; a.cin = L.cin;
@@ -220,7 +257,28 @@ int launch_gemm_f32(const ConvLayer& L, const float* x, float* y, int B, int H, 
     std::snprintf(pname, sizeof(pname), "gemm_f32<ks%d,tile256x128>", L.ks);
     ProfScope prof(pname, 2.0 * (double)a.M * a.N * a.K,
                    4.0 * ((double)B * H * W * L.cin + (double)a.M * a.N + (double)a.N * a.K), s);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, s, a);
+    OCR_HIP_CHECK(hipGetLastError());
+    return OCRHIP_OK;
+}
+
+int gemm_f32_column_blocks(const ConvLayer& L) { return (L.cout + kBN - 1) / kBN; }
+
+// x: (M, cin) -> per row and column block of 128 the largest value of x W^T + bias and its column (see ARGMAX above).
+int launch_gemm_f32_argmax(const ConvLayer& L, const float* x, int64_t M, float* pmax, int* pidx, hipStream_t s) {
+    OCR_REQUIRE(L.w_gemm.ptr && L.ks == 1, "gemm_f32_argmax: layer not prepared");
+    OCR_REQUIRE(x && pmax && pidx && M > 0 && M < (1ll << 31), "gemm_f32_argmax: bad arguments");
+    GemmArgs a;
+    a.x = x; a.w = L.w_gemm.as<float>(); a.bias = L.bias_gemm.as<float>(); a.y = nullptr; a.pmax = pmax; a.pidx = pidx;
+    a.N = L.cout; a.K = L.cin; a.relu = 0;
+    a.n_blocks = gemm_f32_column_blocks(L);
+    a.H = 1; a.W = (int)M; a.cin = L.cin; a.Hc = 1; a.Wc = (int)M; a.M = M;
+    a.seg_len = L.cin; a.seg_stride = (int)M * L.cin;
+    const int64_t wgs = (a.M + kBM - 1) / kBM * a.n_blocks;
+    OCR_REQUIRE(wgs < (1ll << 31), "gemm_f32_argmax: too many workgroups");
+    ProfScope prof("gemm_f32_argmax<tile256x128>", 2.0 * (double)a.M * a.N * a.K,
+                   4.0 * ((double)M * L.cin + 2.0 * (double)a.M * a.n_blocks + (double)a.N * a.K), s);
+    hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }

@@ -165,6 +165,47 @@ def test_crnn_other_lstm_widths_match_oracle(ctx, hidden, backbone):
         ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=V, seed=2))
 
 
+@pytest.mark.parametrize('V', [97, 128, 129, 6719])
+def test_greedy_tokens_without_logits_equal_the_decoding_of_the_logits(ctx, V):
+    """Tokens without a logits request (the class layer hands per-block maxima to the CTC kernel, no logits in
+    memory) == tokens and scores decoded from the logits the same call writes when asked, bit for bit; uniform and
+    ragged calls, vocabularies of one block, exactly one block, one block + 1 and 53 blocks of 128 classes."""
+    from oracle import ctc as octc
+    params = nets.init_crnn_params(vocab_size=V, seed=9)
+    rng = np.random.default_rng(V)
+    # duplicate class rows: exact ties inside a block and across blocks, the first class must win
+    w, b = params['Prediction.weight'], params['Prediction.bias']
+    for dst, src in ((5, 3), (V - 1, 3), (V // 2, 1)):
+        w[dst], b[dst] = w[src], b[src]
+    ctx.crnn_load_weights(params)
+    try:
+        def blocks(w):          # coarse random patterns: the argmax changes along the sequence (white noise gives one class)
+            return np.kron(rng.uniform(-1, 1, (4, w // 16)), np.ones((16, 16))).astype(np.float32)
+        x = torch.from_numpy(np.stack([blocks(160) for _ in range(9)])[..., None]).cuda()
+        full = ctx.crnn_forward(x, want_logits=True, want_tokens=True)
+        fused = ctx.crnn_forward(x, want_logits=False, want_tokens=True)
+        torch.cuda.synchronize()
+        rt, rs = octc.ctc_greedy(full['logits'].cpu().numpy(), None, 0)
+        for out in (full, fused):
+            np.testing.assert_array_equal(out['tokens'].cpu().numpy(), rt)
+            np.testing.assert_array_equal(out['scores'].cpu().numpy(), rs)
+        widths = np.array([64] * 5 + [128] * 300 + [320] * 2, dtype=np.int32)
+        packed = torch.from_numpy(np.concatenate([blocks(int(w)).reshape(-1) for w in widths])).cuda()
+        a = ctx.crnn_forward_packed(packed, widths, want_logits=True)
+        f = ctx.crnn_forward_packed(packed, widths, want_logits=False)
+        ctx.set_option('fuse_ctc', 0)
+        u = ctx.crnn_forward_packed(packed, widths, want_logits=False)
+        torch.cuda.synchronize()
+        ctx.check_errors()
+        for out in (f, u):
+            np.testing.assert_array_equal(out['tokens'].cpu().numpy(), a['tokens'].cpu().numpy())
+            np.testing.assert_array_equal(out['scores'].cpu().numpy(), a['scores'].cpu().numpy())
+        assert len(np.unique(a['tokens'].cpu().numpy())) >= 4          # a real mixture of classes and padding
+    finally:
+        ctx.set_option('fuse_ctc', 1)
+        ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=97, seed=2))
+
+
 def test_lstm_handover_timeout_is_an_error_not_output(ctx):
     """A persistent recurrence whose workgroups cannot hand over (here: one of them withholds its first hand-over
     through the test hook) must fail the call loudly, and the handle must work again afterwards."""

@@ -246,7 +246,7 @@ def test_crop_resize_pack_matches_oracle(ctx):
 
 # ----------------------------------------------------------------------------- CTC greedy
 
-@pytest.mark.parametrize('B,T,V', [(7, 40, 97), (3, 63, 6719), (2, 1, 5), (1, 300, 97)])
+@pytest.mark.parametrize('B,T,V', [(7, 40, 97), (3, 63, 6719), (2, 1, 5), (1, 300, 97), (3, 2351, 97), (2, 4100, 11)])
 def test_ctc_greedy_matches_oracle(ctx, B, T, V):
     rng = np.random.default_rng(B * 1000 + T)
     logits = rng.normal(0, 1, (B, T, V)).astype(np.float32)
