@@ -32,42 +32,43 @@ def _is_path(data):
     return len(glob.glob(data)) > 0
 
 
+def _array_to_json(data):
+    data = data.detach().cpu().numpy() if hasattr(data, 'detach') else np.asarray(data)
+    if data.ndim == 0:
+        return to_json(data.item())
+    if data.size >= 256:
+        logger.warning('Serialising an array of shape %s to json', data.shape)
+    return [to_json(d) for d in data]
+
+
+# (test, conversion) pairs tried in order; the first test that holds decides.  The order matters where types nest:
+# bool before int (bool is an int), arrays before sequences, enums before anything their value could match.
+_JSON_RULES = (
+    (lambda d: d is None or isinstance(d, bool), lambda d: d),
+    (lambda d: isinstance(d, enum.Enum), lambda d: to_json(d.name)),
+    (lambda d: hasattr(d, 'shape'), _array_to_json),
+    (lambda d: isinstance(d, bytes), lambda d: to_json(d.decode('utf-8'))),
+    (lambda d: isinstance(d, uuid.UUID), str),
+    (lambda d: isinstance(d, datetime.datetime), lambda d: d.strftime('%Y-%m-%d %H:%M:%S')),
+    (lambda d: isinstance(d, (float, np.floating)), float),
+    (lambda d: isinstance(d, (int, np.integer)), int),
+    (lambda d: isinstance(d, (list, tuple, set)), lambda d: [to_json(x) for x in d]),
+    (lambda d: isinstance(d, dict), lambda d: {to_json(k): to_json(v) for k, v in d.items()}),
+    (lambda d: isinstance(d, str), lambda d: d.replace('\\', '/') if _is_path(d) else d),
+    (lambda d: hasattr(d, 'get_config'), lambda d: to_json(d.get_config())),
+    (lambda d: callable(d) and hasattr(d, '__name__'), lambda d: d.__name__),
+)
+
+
 def to_json(data):
-    """utils/generic_utils.py:72-104 for the types a result dictionary holds: arrays / tensors -> nested lists of
-    Python floats or ints (float32 widened to double, as `float()` does), existing paths -> '/' separators."""
-    if data is None:
-        return data
-    if isinstance(data, enum.Enum):
-        data = data.name
-    elif hasattr(data, 'shape'):
-        data = data.detach().cpu().numpy() if hasattr(data, 'detach') else np.asarray(data)
-        if data.ndim == 0:
-            data = data.item()
-        elif int(np.prod(data.shape)) >= 256:
-            logger.warning('Large array of shape %s is serialized to json !', data.shape)
-    if isinstance(data, bytes):
-        data = data.decode('utf-8')
-    if isinstance(data, bool):
-        return data
-    if isinstance(data, uuid.UUID):
-        return str(data)
-    if isinstance(data, datetime.datetime):
-        return data.strftime('%Y-%m-%d %H:%M:%S')
-    if isinstance(data, (float, np.floating)):
-        return float(data)
-    if isinstance(data, (int, np.integer)):
-        return int(data)
-    if isinstance(data, (list, tuple, set, np.ndarray)):
-        return [to_json(d) for d in data]
-    if isinstance(data, dict):
-        return {to_json(k): to_json(v) for k, v in data.items()}
-    if isinstance(data, str):
-        return data.replace('\\', '/') if _is_path(data) else data
-    if hasattr(data, 'get_config'):
-        return to_json(data.get_config())
-    if callable(data) and hasattr(data, '__name__'):
-        return data.__name__
-    logger.warning('Unknown json data (%s) : %s', type(data), data)
+    """Anything a result dictionary holds -> what `json.dump` accepts, with the reference's conventions
+    (utils/generic_utils.py:72-104): arrays / tensors become nested lists of Python numbers (float32 widened to
+    double, as `float()` does), enums their name, datetimes 'Y-m-d H:M:S', strings that name existing files get '/'
+    separators, objects with `get_config()` their config, functions their name; anything else `str()` with a warning."""
+    for applies, convert in _JSON_RULES:
+        if applies(data):
+            return convert(data)
+    logger.warning('No json form for %s (%r): stored as str', type(data).__name__, data)
     return str(data)
 
 
