@@ -4,7 +4,8 @@ models/ocr/crnn.py:15-58), running on libocrhip.so.
 Same defaults as the reference (`combine=True`, `method='beam_search'`, 10 beams).  Beam search runs on
 the host from the GPU logits; `method='greedy'` decodes on the GPU.  Callbacks and the `map.json` prediction cache
 (`predict(save=True)`) work as in the reference (utils/saving.py), so do `box_filters` (utils/filters.py);
-`dezoom_factor`, the image saver, the displayer and camera streaming are not built (NotImplementedError, never a silent change).
+`dezoom_factor` scales every row's pixel box about its centre before the crop, as the reference does; the image saver,
+the displayer and camera streaming are not built.
 """
 import logging
 import os
@@ -64,23 +65,23 @@ class BaseOCR:
         return self.model
 
     # ---- one row, as the reference prepares it (base_image_model.py:93-131 with use_box=True)
-    def get_input(self, data, **kwargs):
+    def get_input(self, data, dezoom_factor=1., **kwargs):
         """{'filename': image, 'boxes': {'boxes': row, 'format': 'xyxy'}} -> (64, Wpad, 1) float32 GPU tensor
         (a tensor with a zero dimension for an empty crop)."""
         image = load_image(data)
         boxes = data['boxes']['boxes'] if isinstance(data['boxes'], dict) else data['boxes']
         out = self._pack(torch.from_numpy(np.ascontiguousarray(image)).to(self.ctx.device)[None],
-                         [np.asarray(boxes, dtype=np.float32).reshape(-1, 4)[:1]])
+                         [np.asarray(boxes, dtype=np.float32).reshape(-1, 4)[:1]], dezoom_factor=dezoom_factor)
         if out is None:
             return torch.zeros((64, 0, 1), device=self.ctx.device)
         packed, plan, off = out
         return packed.view(64, int(plan['out_w'][0]), 1)
 
-    def _pack(self, d_images, boxes_per_image):
+    def _pack(self, d_images, boxes_per_image, dezoom_factor=1.):
         B, H, W, _ = d_images.shape
         plans, box_img = [], []
         for b, boxes in enumerate(boxes_per_image):
-            p = plan_crops(boxes, H, W)
+            p = plan_crops(boxes, H, W, dezoom_factor=dezoom_factor)
             plans.append(p)
             box_img.append(np.full(len(p['index']), b, dtype=np.int32))
         plan = {k: np.concatenate([p[k] for p in plans]) for k in ('rects', 'inter', 'out_w', 'index')}
@@ -96,7 +97,7 @@ class BaseOCR:
             torch.from_numpy(off[:-1].astype(np.int64)).to(dev), int(off[-1]))
         return packed, plan, off
 
-    def recognise_rows(self, image, rows, method='greedy', num_beams=10):
+    def recognise_rows(self, image, rows, method='greedy', num_beams=10, dezoom_factor=1.):
         """All rows of one image in one go -> (index of valid rows, texts, scores).
 
         method 'greedy': argmax + collapse on the GPU.  method 'beam_search' / 'beam': the logits come
@@ -109,7 +110,7 @@ class BaseOCR:
         if image.shape[2] == 1:
             image = np.repeat(image, 3, axis=2)
         d_img = torch.from_numpy(np.ascontiguousarray(image)).to(self.ctx.device)[None]
-        out = self._pack(d_img, [np.asarray(rows, dtype=np.float32).reshape(-1, 4)])
+        out = self._pack(d_img, [np.asarray(rows, dtype=np.float32).reshape(-1, 4)], dezoom_factor=dezoom_factor)
         if out is None:
             return [], [], np.zeros((0,), np.float32)
         packed, plan, off = out
@@ -150,8 +151,6 @@ class BaseOCR:
             if callbacks:
                 apply_callbacks(callbacks, predicted[data], {}, save=False)
             return predicted[data]
-        if dezoom_factor != 1.:
-            raise NotImplementedError('dezoom_factor is not available in this build')
         filename, image = get_image_data(data)
         if not isinstance(data, dict) or 'boxes' not in data:
             if isinstance(detector, str):
@@ -173,7 +172,8 @@ class BaseOCR:
             boxes, _, rows = filter_boxes(box_filters, boxes, list(range(len(boxes))), rows)
         flat_rows = np.concatenate(rows).reshape(-1, 4) if rows else np.zeros((0, 4), np.float32)
         owner = np.concatenate([np.full(len(r), i) for i, r in enumerate(rows)]) if rows else np.zeros((0,), int)
-        index, texts, scores = self.recognise_rows(np.asarray(image), flat_rows, method=method, num_beams=num_beams)
+        index, texts, scores = self.recognise_rows(np.asarray(image), flat_rows, method=method, num_beams=num_beams,
+                                                   dezoom_factor=dezoom_factor)
         if len(flat_rows) - len(index):
             logger.warning('Invalid input encountered : %d empty crops skipped', len(flat_rows) - len(index))
         ocr_results = []

@@ -86,7 +86,10 @@ class HIPRuntime:
             out = self.engine.ctx.east_forward(t)
         else:
             out = self.engine.ctx.crnn_forward(t.float().contiguous(), want_logits=True)['logits']
-        return out.cpu().numpy() if as_numpy else out
+        if as_numpy:
+            out = out.cpu().numpy()
+            self.engine.ctx.check_errors(synchronize=False)     # a failed recurrence raises instead of returning garbage
+        return out
 
 
 _runtimes = {'hip': HIPRuntime}

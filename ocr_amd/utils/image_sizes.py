@@ -61,12 +61,31 @@ def _resolve_index(v, size):
     return np.clip(v, 0, size)
 
 
-def plan_crops(boxes_rel, image_h, image_w, height=64, multiple=64):
+def dezoom_absolute(abs_boxes, factor, image_h, image_w):
+    """int32 pixel xyxy boxes scaled about their centres by `factor`, as `crop_box(..., dezoom_factor=)` sees them
+    (utils/image/bounding_box/converter.py:202-232 after the conversion to pixels): float32 arithmetic, the new corner
+    and size truncated to int32, the size clipped to the image."""
+    ab = np.asarray(abs_boxes, dtype=np.int32).reshape(-1, 4)
+    x, y = ab[:, 0].astype(np.float32), ab[:, 1].astype(np.float32)
+    w, h = (ab[:, 2] - ab[:, 0]).astype(np.float32), (ab[:, 3] - ab[:, 1]).astype(np.float32)
+    new_h, new_w = h * factor, w * factor
+    nx = np.maximum((x + w / 2.) - new_w / 2., 0).astype(np.int32)
+    ny = np.maximum((y + h / 2.) - new_h / 2., 0).astype(np.int32)
+    nw = np.minimum(new_w.astype(np.int32), image_w - nx)
+    nh = np.minimum(new_h.astype(np.int32), image_h - ny)
+    return np.stack([nx, ny, nx + nw, ny + nh], axis=1)
+
+
+def plan_crops(boxes_rel, image_h, image_w, height=64, multiple=64, dezoom_factor=1.):
     """Everything the crop kernel needs for the boxes of one image (vectorised over the boxes).
 
     Returns dict(rects (m,4) int32, inter (m,2) int32, out_w (m,) int32, index (m,) indices of the
-    boxes that give a non-empty network input)."""
-    ab = relative_to_absolute(boxes_rel, image_h, image_w).astype(np.int64)
+    boxes that give a non-empty network input).  `dezoom_factor` enlarges (> 1) or shrinks the pixel boxes
+    about their centres before the crop (models/ocr/base_ocr.py:178-181)."""
+    ab = relative_to_absolute(boxes_rel, image_h, image_w)
+    if dezoom_factor != 1.:
+        ab = dezoom_absolute(ab, dezoom_factor, image_h, image_w)
+    ab = ab.astype(np.int64)
     x0, x1 = _resolve_index(ab[:, 0], image_w), _resolve_index(ab[:, 2], image_w)
     y0, y1 = _resolve_index(ab[:, 1], image_h), _resolve_index(ab[:, 3], image_h)
     cw, ch = x1 - x0, y1 - y0

@@ -102,8 +102,22 @@ def test_base_ocr_infer_and_ocr_function(models):
     for x, y in zip(g['ocr'], bsr['ocr']):
         np.testing.assert_array_equal(x['boxes'], y['boxes'])
     assert all(-10 < float(r['scores'][0]) <= 0 for r in bsr['ocr'])
-    with pytest.raises(NotImplementedError):
-        crnn.infer({'image': images[0], 'boxes': boxes}, dezoom_factor=2.)
+    # dezoom_factor: every row's pixel box scaled about its centre before the crop (base_ocr.py:178-181 ->
+    # converter.py:202-232) == recognising the boxes the oracle's dezoom gives
+    from ocr_amd.utils.image_sizes import dezoom_absolute, relative_to_absolute
+    dz = crnn.infer({'image': images[0], 'boxes': boxes}, combine=False, method='greedy', dezoom_factor=1.5)
+    H, W = images[0].shape[:2]
+    grown = dezoom_absolute(relative_to_absolute(boxes['boxes'], H, W), 1.5, H, W)
+    ref_texts, ref_logits = [], []
+    for x0, y0, x1, y1 in grown:
+        inp = oimg.prepare_crnn_input(images[0][y0:y1, x0:x1], resize='numpy')
+        lg = __import__('oracle.nets', fromlist=['x']).crnn_forward(cp, inp[None])[0].numpy()
+        ref_logits.append(lg)
+        ref_texts.append(tok.ctc_decode(lg[None])[0][0])
+    assert len(dz['ocr']) == len(ref_texts) and [r['text'] for r in dz['ocr']] != [r['text'] for r in g['ocr']]
+    octc.assert_texts_match_or_tie([r['text'] for r in dz['ocr']], ref_texts, ref_logits, tok)
+    for r, bx in zip(dz['ocr'], boxes['boxes']):
+        np.testing.assert_array_equal(r['boxes'], bx)                      # the reported boxes are the detected ones
 
 
 def test_runtime_object_and_nms_dispatch(models):
@@ -123,3 +137,65 @@ def test_runtime_object_and_nms_dispatch(models):
     boxes, scores, valid = nms(chain, nms_threshold=0.1, merge_threshold=0.1, source='xyxy', method='lanms')
     np.testing.assert_allclose(boxes[valid], [[0, 0, 0.3, 0.3], [0.2, 0.2, 0.5, 0.5]], atol=1e-6)
     assert boxes.shape == (4, 4) and valid.dtype == bool
+
+
+@pytest.mark.parametrize('method', ['tensorflow', 'nms', 'standard', 'fast', 'padded', 'padded_nms'])
+def test_standard_nms_methods(method):
+    """The other methods of the reference's registry (non_max_suppression.py:80-189): its known answer
+    (tests/test_utils_boxes.py:559-584: 4 chained boxes, threshold 0.1 -> keep [0, 2]) and random sets against the
+    oracle's restatement of the matrix iteration."""
+    from ocr_amd.utils.boxes import nms
+    from oracle import nms as onms
+    chain = np.array([[0, 0, 0.2, 0.2], [0.1, 0.1, 0.3, 0.3], [0.2, 0.2, 0.4, 0.4], [0.3, 0.3, 0.5, 0.5]], 'float32')
+    boxes, _, valid = nms(chain, nms_threshold=0.1, source='xyxy', method=method)
+    np.testing.assert_array_equal(boxes[valid], chain[[0, 2]])
+    with pytest.raises(ValueError):
+        nms(chain, nms_threshold=0.1, source='xyxy', method='no_such_method')
+    rng = np.random.default_rng(17)
+    for trial in range(6):
+        n = int(rng.integers(2, 400))
+        xy = rng.uniform(0, 0.8, (n, 2)).astype(np.float32)
+        b = np.concatenate([xy, xy + rng.uniform(0.02, 0.3, (n, 2)).astype(np.float32)], axis=1)
+        sc = (rng.permutation(n).astype(np.float32) + 1) / n
+        thr = float(rng.choice([0.1, 0.25, 0.5]))
+        max_out = None if trial % 2 else 7
+        rb, rs, rv, order = onms.fast_nms(b, sc, max_output_size=max_out, nms_threshold=thr)
+        got_b, got_s, got_v = nms(b, sc, max_out, thr, method=method, source='xyxy')
+        if method == 'tensorflow':                        # input order, boxes untouched
+            np.testing.assert_array_equal(got_b, b)
+            np.testing.assert_array_equal(np.nonzero(got_v)[0], np.sort(order[rv]))
+        else:                                             # score order, dropped boxes zeroed
+            np.testing.assert_array_equal(got_b, rb)
+            np.testing.assert_array_equal(got_s, rs)
+            np.testing.assert_array_equal(got_v, rv)
+
+
+def test_checkpoint_files_round_trip_through_the_runtime(tmp_path):
+    """`HIPRuntime(<file>.pth)`: the torch checkpoints of the original projects (DataParallel `module.` prefixes,
+    `num_batches_tracked` counters) loaded from disk give bit for bit the outputs of the same parameters handed over
+    in memory, for the detector and for the recogniser (VGG and ResNet extractors)."""
+    from ocr_amd.runtimes import HIPRuntime
+    from ocr_amd.weights import random_crnn_params, random_east_params
+    rng = np.random.default_rng(5)
+    cases = [('east', random_east_params(8), rng.integers(0, 256, (1, 96, 128, 3), dtype=np.uint8)),
+             ('crnn_vgg', random_crnn_params(97, seed=9), rng.uniform(-1, 1, (2, 64, 128, 1)).astype(np.float32)),
+             ('crnn_resnet', random_crnn_params(211, hidden=512, seed=10, backbone='resnet'),
+              rng.uniform(-1, 1, (2, 64, 96, 1)).astype(np.float32))]
+    for name, params, x in cases:
+        saved = {'module.' + k: v for k, v in params.items()}
+        bn = [k for k in saved if k.endswith('running_mean')]
+        for k in bn:
+            saved[k.replace('running_mean', 'num_batches_tracked')] = torch.tensor(77)
+        path = str(tmp_path / (name + '.pth'))
+        torch.save(saved, path)
+        from_file = HIPRuntime(path)
+        in_memory = HIPRuntime('state_dict:' + name, state_dict=params, reload=True)
+        assert from_file.engine.kind == ('east' if name == 'east' else 'crnn')
+        a, b = from_file(x), in_memory(x)
+        assert isinstance(a, np.ndarray) and np.isfinite(a).all() and float(np.abs(a).max()) > 0
+        np.testing.assert_array_equal(a, b)
+        assert HIPRuntime(path).engine is from_file.engine               # cached per path
+        from_file.engine.ctx.close()
+        in_memory.engine.ctx.close()
+        HIPRuntime._engines.pop(path, None)
+        HIPRuntime._engines.pop('state_dict:' + name, None)

@@ -118,3 +118,46 @@ def test_easyocr_character_tables():
     assert tok.decode(ids + [0, 0, 5]) == '中文OCR'
     with pytest.raises(ValueError):
         get_characters('klingon_g9')
+
+
+def test_dezoom_matches_reference_vectors_and_known_answers():
+    """`dezoom_factor` of convert_box_format / crop_box: vectors made by the reference's own function
+    (tests/golden/make_dezoom_golden.py) and its known answers (tests/test_utils_boxes.py:116-135)."""
+    import os
+    from conftest import GOLDEN_DIR
+    from ocr_amd.utils.boxes import convert_box_format
+    from ocr_amd.utils.image_sizes import dezoom_absolute, relative_to_absolute
+    g = np.load(os.path.join(GOLDEN_DIR, 'dezoom_golden.npz'))
+    H, W = [int(v) for v in g['image_hw']]
+    for f in g['factors']:
+        f = float(f)
+        rel = convert_box_format(g['boxes'], target='xyxy', source='xyxy', dezoom_factor=f)
+        np.testing.assert_array_equal(rel, g['rel_%g' % f])
+        ab = convert_box_format(g['boxes'], target='xyxy', source='xyxy', dezoom_factor=f, normalize_mode='absolute',
+                                image_h=H, image_w=W)
+        assert ab.dtype == np.int32
+        np.testing.assert_array_equal(ab, g['abs_%g' % f])
+        # the crop planner's own copy of the pixel arithmetic
+        np.testing.assert_array_equal(dezoom_absolute(relative_to_absolute(g['boxes'], H, W), f, H, W), g['abs_%g' % f])
+    kat = lambda box, f: convert_box_format(np.array(box), source='xywh', dezoom_factor=f)
+    np.testing.assert_allclose(kat([0., 0., 1., 1.], 0.5), [[0.25, 0.25, 0.5, 0.5]], atol=1e-6)
+    np.testing.assert_allclose(kat([0., 0., 1., 1.], 2), [[0, 0, 1, 1]], atol=1e-6)
+    np.testing.assert_allclose(kat([0.25, 0.25, .5, .5], 2), [[0, 0, 1, 1]], atol=1e-6)
+    np.testing.assert_allclose(kat([0.5, 0.5, .5, .5], 2), [[0.25, 0.25, .75, .75]], atol=1e-6)
+
+
+def test_load_checkpoint_reads_the_files_the_original_projects_ship(tmp_path):
+    """torch checkpoints as EasyOCR / SakuraRiven save them: `module.` prefixes of DataParallel, batch-norm
+    `num_batches_tracked` counters, optionally nested under 'state_dict'; read with the weights-only loader."""
+    import torch
+    from ocr_amd.weights import load_checkpoint, random_crnn_params
+    params = random_crnn_params(97, seed=3)
+    saved = {'module.' + k: v for k, v in params.items()}
+    saved['module.FeatureExtraction.ConvNet.12.num_batches_tracked'] = torch.tensor(1234)
+    for name, obj in (('flat.pth', saved), ('nested.pth', {'state_dict': saved, 'epoch': 3})):
+        path = str(tmp_path / name)
+        torch.save(obj, path)
+        got = load_checkpoint(path)
+        assert set(got) == set(params) | {'FeatureExtraction.ConvNet.12.num_batches_tracked'}
+        for k, v in params.items():
+            assert torch.equal(got[k], v)

@@ -66,7 +66,7 @@ def test_predict_resumes_from_map_json(tmp_path, monkeypatch):
         def __init__(self):
             self.name = 'stub'
 
-        def recognise_rows(self, image, rows, method='greedy', num_beams=10):
+        def recognise_rows(self, image, rows, method="greedy", num_beams=10, dezoom_factor=1.):
             calls.append(len(rows))
             return list(range(len(rows))), ['w%d' % i for i in range(len(rows))], np.full(len(rows), -0.5, np.float32)
 
