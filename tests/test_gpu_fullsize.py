@@ -95,3 +95,31 @@ def test_decode_order_and_ctc_invariants(setup):
         L = int(lengths[i])
         ref = [int(v) for k, v in enumerate(am[i, :L]) if v != 0 and (k == 0 or v != am[i, k - 1])]
         assert t.tolist() == ref
+
+
+def test_decode_and_lanms_on_the_networks_own_maps_at_full_size(setup):
+    """The detector's OWN output at 1024x1024 (random weights: scores hover around 0.5 and geometry / angles are
+    arbitrary, so rotated boxes, boxes leaving the page and dense overlaps all occur) through decode + LANMS + NMS,
+    against the oracle on the same maps.  The threshold is set so that 20 000 pixels pass it (about a tenth of them survive the validity filter)."""
+    from oracle import boxes as obox, east_decode, lanms_c
+    pipe, d_img, _ = setup
+    ctx = pipe.ctx
+    maps = ctx.east_forward(d_img)
+    h_maps = maps.cpu().numpy()
+    for b in range(2):
+        thr = float(np.quantile(h_maps[b, ..., 0], 1.0 - 20000.0 / h_maps[b, ..., 0].size))
+        dec = ctx.east_decode(maps[b:b + 1], (1024, 1024), threshold=thr, with_pix=True)
+        out = ctx.lanms(dec['xyxy'], dec['scores'], dec['counts'], merge_threshold=0.3, nms_threshold=0.2)
+        torch.cuda.synchronize()
+        n = int(dec['counts'][0])
+        ref = east_decode.decode_map(h_maps[b], (1024, 1024), threshold=thr, trig='rounded64', return_index=True)
+        assert n == len(ref['boxes']) and 500 <= n <= 20000
+        np.testing.assert_array_equal(dec['pix'][0, :n].cpu().numpy(), ref['index'])
+        xy = dec['xyxy'][0, :n].cpu().numpy()
+        np.testing.assert_array_equal(xy, obox.poly_to_xyxy(ref['boxes']))
+        sc = dec['scores'][0, :n].cpu().numpy()
+        rb, rs, rmask, _, r_iter = lanms_c.lanms(xy, sc, None, 0.2, merge_threshold=0.3, merge_method='union')
+        m = int(out['counts'][0])
+        assert m == int(rmask.sum()) and int(out['n_iter'][0]) == r_iter
+        np.testing.assert_array_equal(out['boxes'][0, :m].cpu().numpy(), rb[rmask])
+        np.testing.assert_array_equal(out['scores'][0, :m].cpu().numpy(), rs[rmask])
