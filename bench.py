@@ -142,10 +142,12 @@ def hbm_rooflines(stats, acct, vocab, steps):
         'lanms': 2 * 20.0 * acct['decode_candidates'],
         # 3 B x crop source pixels read + 4 B x 64 x Wpad written
         'crop_resize_pack': 3.0 * acct['crop_src_px'] + 4.0 * acct['crop_out_elems'],
-        # 4 B x T x V logits read + 4 B x T tokens written
+        # 4 B x T x V logits read + 4 B x T tokens written (the path that writes logits: fuse_ctc=0, bf16)
         'ctc_greedy': 4.0 * acct['ctc_rows'] * (vocab + 1),
+        # greedy decoding fused into the class layer: 8 B per row and block of 128 classes read + 4 B x T written
+        'ctc_greedy_partial': 4.0 * acct['ctc_rows'] * (2 * ((vocab + 127) // 128) + 1),
     }
-    pmc_names = {'east_decode': ['east_decode_flags', 'east_decode_write']}
+    pmc_names = {'east_decode': ['east_decode_flags', 'east_decode_write'], 'ctc_greedy_partial': ['ctc_greedy']}
     out = []
     for name, nbytes in per_launch.items():
         s = by.get(name)
