@@ -95,6 +95,7 @@ struct ConvLayer {
     DevBuf w_bf16;          // bfloat16 slab of the same layer (see conv_bf16.hip), when cin % 16 == 0
     DevBuf w_wino;          // 3x3 layers with >= 64 output channels: Winograd-transformed filters (see conv_wino.hip)
     DevBuf w_wino4;         // the same layers: F(4x4,3x3)-transformed filters (see conv_wino4.hip)
+    DevBuf w_wino4b;        // layers with < 256 input channels: the same filters in the layout of that kernel's MODE 3
     DevBuf bias;            // cout_pad floats, folded
     DevBuf w_gemm, bias_gemm;   // 1x1 and 2x2 layers: slabs and bias for the 256 x 128 flat GEMM (see gemm_f32.hip)
     bool direct = false;    // small-Cin direct kernel layout
@@ -152,6 +153,7 @@ struct ocrhip_ctx {
     int lstm_debug_drop = 0;       // test hook: the persistent recurrence withholds one hand-over and times out quickly
     int lstm_persistent = 1;       // recurrence of a BiLSTM layer in one persistent launch (1) or one launch per step (0)
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
+    int wino4_wave_tiles = 1;      // F(4x4,3x3) layers with < 256 input channels: waves own whole (block, channel) tiles, inverse transform in registers (1) or the 3x3-component split with staged partial sums (0)
     int wino4_split = 1;           // F(4x4,3x3) layers with >= 256 input channels: transform once into `wino_ws`, multiply from it (1) or fused (0)
     ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
     int fuse_ctc = 1;              // tokens without a logits request: class layer reduced to per-block maxima in its epilogue (1) or logits written and re-read (0)
@@ -193,6 +195,8 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
                       const float* residual, hipStream_t s);
 DevBuf* current_workspace();         // grow-only scratch of the handle in use on this thread (transformed tiles), or nullptr
 void set_current_workspace(DevBuf* ws);
+int wino4_wave_tiles();              // option of the handle in use on this thread
+void set_wino4_wave_tiles(int on);
 int wino4_split();                   // option of the handle in use on this thread
 void set_wino4_split(int on);
 int conv3x3_winograd();              // option of the handle in use on this thread

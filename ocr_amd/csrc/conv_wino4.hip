@@ -15,9 +15,10 @@
 // blocks of 4x4, times 64 output channels.  The 36 Winograd components are 36 independent GEMMs (32 blocks x Cin) x
 // (Cin x 64); wave (gr, gc, ch) owns the 3x3 components (3 gr + 0..2, 3 gc + 0..2) for 32 blocks x channels
 // 32 ch .. 32 ch + 31: 9 accumulators of 32x32 = 144 registers.
-//   K: chunks of 8 input channels.  The raw tile with its halo (18 x 34 pixels) is staged in LDS, transformed into
-//   U[component][block][channel] in LDS by all threads (task = (block, channel pair, component row): a row of B^T d,
-//   then (.) B along it), and every lane loads its transformed-filter fragments straight from a lane-linear slab.
+//   K: chunks of 8 input channels.  The raw tile with its halo (18 x 34 pixels, 40 bytes per pixel so that the blocks a
+//   half-wave reads fall into different banks) is staged in LDS, transformed into U[component][block][channel] in LDS by
+//   all threads (lane = (block, channel pair), wave = (half of the tile, one or two component rows): rows of B^T d,
+//   then (.) B along them), and every lane loads its transformed-filter fragments straight from a lane-linear slab.
 //   U and the raw tile are double buffered, one barrier per chunk; a wave transforms chunk k + 1 and then multiplies
 //   chunk k, so while one wave of a SIMD is in its transform the other one has MFMAs to issue.
 //   Epilogue, one block row (4 x 32 outputs) at a time: each wave applies its share of the inverse transform (A^T
@@ -41,7 +42,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 constexpr int kCK = 8;                          // input channels per chunk
-constexpr int kRS = 12;                         // floats per raw pixel in LDS
+constexpr int kRS = 10;                         // floats per raw pixel in LDS: 8 channels + 2, so that the 8 blocks a half-wave reads (4 pixels apart) start 8 banks apart
 constexpr int kRawW = 34, kRawH = 20, kRawPx = kRawW * kRawH;      // 18 rows of one image, or 2 x 10 of a stacked pair
 constexpr int kRFloats = kRawPx * kRS;
 constexpr int kRBuf = kRFloats + 4;             // + a spare slot for the threads without a pixel
@@ -53,6 +54,7 @@ constexpr int kPartFloats = 128 * kOS;          // one wave group's share of a b
 constexpr int kStageFloats = 4 * kPartFloats;
 constexpr int kLdsBytes = 4 * (kLoopFloats > kStageFloats ? kLoopFloats : kStageFloats);
 constexpr int kWChunkFloats = 36 * 2 * 64 * 4;  // transformed filters of one chunk of one 64-channel block
+constexpr int kSplitMinCin = 256;               // layers at least this deep run as transform kernel + multiply kernel
 
 struct Wino4Args {
     const float* x;        // (B,H,W,cin)
@@ -107,6 +109,15 @@ __device__ __forceinline__ void inverse_part(const float (&M)[3][3], float (&Y)[
 //   MODE 2 multiplies only: the MFMA operands of both sides come straight from memory (v and the filter slab, 16 bytes
 //          per lane, reloaded for the next chunk right after their last use): no LDS, no barrier and no vector-ALU work
 //          in the chunk loop; LDS serves the epilogue alone.
+//   MODE 3 is the fused kernel with a different division of the work between the waves, used for the shallow layers
+//          (< 256 input channels: few chunks, so the epilogue weighs most).  The multiplications run on
+//          v_mfma_f32_16x16x4_f32 and wave (bh, cq) owns ALL 36 components of 16 blocks x 16 channels (36 accumulators of
+//          4 registers: the same 144).  A lane then holds the complete 6x6 product of its (block, channel) elements: the
+//          inverse transform and the max-pool happen in registers, the workgroup stages its (pooled) tile in LDS once
+//          and passes ONE barrier before the 16-byte stores - against four partial sums per output, staged one block
+//          row at a time between eight barriers, in MODE 0.  The price: a block's transformed data is read from LDS by
+//          four waves instead of two, and a filter fragment is loaded by two waves instead of one (both have room).
+//          Same arithmetic as MODE 0 up to the order of the additions in the inverse transform.
 template <int POOL, int MODE>
 __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // U[2] then raw[2]: chunk j lives in buffer j & 1
@@ -134,11 +145,19 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     floatx4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE != 1) bias4 = *reinterpret_cast<const floatx4*>(a.bias + co0);          // bias is padded to cout_pad
 
-    floatx16 acc[9];
+    floatx16 acc[MODE == 3 ? 1 : 9];
+    floatx4 acc3[MODE == 3 ? 36 : 1];           // MODE 3: component f of blocks 16 bh + 4 (lane / 16) + v, channel 16 cq + lane % 16
+    if constexpr (MODE == 3) {
 #pragma unroll
-    for (int f = 0; f < 9; ++f)
+        for (int f = 0; f < 36; ++f)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[f][v] = 0.0f;
+            for (int v = 0; v < 4; ++v) acc3[f][v] = 0.0f;
+    } else {
+#pragma unroll
+        for (int f = 0; f < 9; ++f)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[f][v] = 0.0f;
+    }
 
     // Global loads go through buffer descriptors: a per-lane byte offset that never changes, the chunk as a scalar
     // offset, and the range check, which returns zeros beyond the buffer: the zero padding around the image costs no
@@ -177,24 +196,55 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     };
     auto store_raw = [&](int rbase) {
 #pragma unroll
-        for (int i = 0; i < NRAW; ++i) *reinterpret_cast<float4*>(&lds[rbase + raw_dst[i]]) = ra[i];
+        for (int i = 0; i < NRAW; ++i) {          // pixels are 40 bytes apart: two 8-byte stores
+            *reinterpret_cast<floatx2*>(&lds[rbase + raw_dst[i]]) = floatx2{ra[i].x, ra[i].y};
+            *reinterpret_cast<floatx2*>(&lds[rbase + raw_dst[i] + 2]) = floatx2{ra[i].z, ra[i].w};
+        }
     };
 
-    // Data transform.  Wave task wt in [0, 12) = (block-row half, component row i); its lanes = (block row within the
-    // half, block column, channel pair).  A lane forms row i of B^T d for its block (6 columns, each a combination of
-    // 3 or 4 raw rows) and multiplies by B along the row: components (i, 0..5) of 2 channels.  Wave w runs task w, waves
-    // 0..3 also task 8 + w (every SIMD gets three tasks).  i is uniform in a wave: the code is specialised per row,
+    // Data transform.  A wave task = (block-row half, component rows): its lanes = (block row within the half, block
+    // column, channel pair).  A lane forms its rows of B^T d for its block (6 columns, each a combination of 3 or 4 raw
+    // rows) and multiplies by B along each row: components (i, 0..5) of 2 channels,
     //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1].
+    // Rows 1 and 2 are (d4 - 4 d2) +- (d3 - 4 d1), rows 3 and 4 are (d4 - d2) +- 2 (d3 - d1): a task that forms both
+    // rows of such a pair reads its four raw rows once.  Eight tasks, one per wave: waves 0..3 take the row pairs (1, 2)
+    // and (3, 4) of the two halves, waves 4..7 the single rows 0 and 5, so that every SIMD (waves s and s + 4) gets one
+    // pair task and one single task.  The roles are uniform in a wave: the code is specialised per role.
     const int t_p = lane & 3, t_bx = (lane >> 2) & 7, t_bylo = lane >> 5;
-    auto transform_task = [&](int wt, int rbase, int ubase) {
-        const int i = wt % 6, by = (wt / 6) * 2 + t_bylo;
+    auto transform = [&](int rbase, int ubase) {
+        const int half = wave & 1, role = wave >> 1;       // role 0: rows 1, 2; 1: rows 3, 4; 2: row 0; 3: row 5
+        const int by = half * 2 + t_bylo;
         const int m = by * 8 + t_bx;
         const float* src = &lds[rbase + ((by * 4 + (pair ? 2 * (by >> 1) : 0)) * kRawW + t_bx * 4) * kRS + t_p * 2];
         constexpr int RW = kRawW * kRS;
         auto rd = [&](int r, int c) { return *reinterpret_cast<const floatx2*>(src + r * RW + c * kRS); };
-        floatx2 t[6];
-        if (i == 0 || i == 5) {                    // 4 d_a - 5 d_b + d_c with rows (0, 2, 4) or (1, 3, 5)
-            const int ra_ = i == 0 ? 0 : RW;
+        // (.) B along a row t[0..5] of B^T d, written as components (i, 0..5)
+        auto row_out = [&](const floatx2 (&t)[6], int i) {
+            const floatx2 e1 = t[4] - 4.0f * t[2], e2 = t[3] - 4.0f * t[1], e3 = t[4] - t[2], e4 = t[3] - t[1];
+            floatx2 o[6];
+            o[0] = 4.0f * t[0] + (t[4] - 5.0f * t[2]);
+            o[1] = e1 + e2;
+            o[2] = e1 - e2;
+            o[3] = e3 + 2.0f * e4;
+            o[4] = e3 - 2.0f * e4;
+            o[5] = 4.0f * t[1] + (t[5] - 5.0f * t[3]);
+            if constexpr (MODE == 3) {
+                // MODE 3: components in pairs, U[f / 2][block][channel pair][f % 2][2 channels]: a lane's operands for two
+                // components are one 16-byte read, and a wave's reads tile 1 KB without gaps
+                float* dst3 = &lds[ubase + (i * 3) * (2 * kUC) + m * (2 * kCK) + t_p * 4];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<floatx2*>(dst3 + (j >> 1) * (2 * kUC) + (j & 1) * 2) = o[j];
+            } else {
+                // U[component][block m][8 channels]; the two 16-byte halves of a block swap places in blocks 8..15 and
+                // 24..31, which makes the MFMA operand reads (16 lanes = 16 blocks, one half) conflict free without padding
+                float* dst = &lds[ubase + (i * 6) * kUC + m * kCK + (((t_p >> 1) ^ ((m >> 3) & 1)) * 4) + (t_p & 1) * 2];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<floatx2*>(dst + j * kUC) = o[j];
+            }
+        };
+        if (role >= 2) {                               // 4 d_a - 5 d_b + d_c with rows (0, 2, 4) or (1, 3, 5)
+            const int ra_ = role == 2 ? 0 : RW;
+            floatx2 t[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const floatx2 da = *reinterpret_cast<const floatx2*>(src + ra_ + c * kRS);
@@ -202,33 +252,20 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
                 const floatx2 dc = *reinterpret_cast<const floatx2*>(src + ra_ + 4 * RW + c * kRS);
                 t[c] = 4.0f * da + (dc - 5.0f * db);
             }
-        } else {                                   // (d4 - q d2) + s p (d3 - q d1): q = 4, p = 1 (i = 1, 2); q = 1, p = 2 (i = 3, 4)
-            const float q = i <= 2 ? 4.0f : 1.0f;
-            const float sp = (i <= 2 ? 1.0f : 2.0f) * ((i & 1) ? 1.0f : -1.0f);
+            row_out(t, role == 2 ? 0 : 5);
+        } else {                                       // (d4 - q d2) +- p (d3 - q d1): q = 4, p = 1 (rows 1, 2); q = 1, p = 2 (rows 3, 4)
+            const float q = role == 0 ? 4.0f : 1.0f, pp = role == 0 ? 1.0f : 2.0f;
+            floatx2 ta[6], tb[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const floatx2 e1 = rd(4, c) - q * rd(2, c);
                 const floatx2 e2 = rd(3, c) - q * rd(1, c);
-                t[c] = e1 + sp * e2;
+                ta[c] = e1 + pp * e2;
+                tb[c] = e1 - pp * e2;
             }
+            row_out(ta, 1 + 2 * role);
+            row_out(tb, 2 + 2 * role);
         }
-        const floatx2 e1 = t[4] - 4.0f * t[2], e2 = t[3] - 4.0f * t[1], e3 = t[4] - t[2], e4 = t[3] - t[1];
-        floatx2 o[6];
-        o[0] = 4.0f * t[0] + (t[4] - 5.0f * t[2]);
-        o[1] = e1 + e2;
-        o[2] = e1 - e2;
-        o[3] = e3 + 2.0f * e4;
-        o[4] = e3 - 2.0f * e4;
-        o[5] = 4.0f * t[1] + (t[5] - 5.0f * t[3]);
-        // U[component][block m][8 channels]; the two 16-byte halves of a block swap places in blocks 8..15 and 24..31,
-        // which makes the MFMA operand reads (16 lanes = 16 blocks, one half) conflict free without padding
-        float* dst = &lds[ubase + (i * 6) * kUC + m * kCK + (((t_p >> 1) ^ ((m >> 3) & 1)) * 4) + (t_p & 1) * 2];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<floatx2*>(dst + j * kUC) = o[j];
-    };
-    auto transform = [&](int rbase, int ubase) {
-        transform_task(wave, rbase, ubase);
-        if (wave < 4) transform_task(8 + wave, rbase, ubase);
     };
 
     float4 bw[9], af[MODE == 2 ? 9 : 3];
@@ -299,7 +336,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         for (int f = 0; f < 9; ++f) bw[f] = load_w(0, f);
         store_raw(kR0);
 #pragma unroll
-        for (int i = 0; i < NRAW; ++i) *reinterpret_cast<float4*>(&lds[kR1 + raw_dst[i]]) = rb[i];
+        for (int i = 0; i < NRAW; ++i) {
+            *reinterpret_cast<floatx2*>(&lds[kR1 + raw_dst[i]]) = floatx2{rb[i].x, rb[i].y};
+            *reinterpret_cast<floatx2*>(&lds[kR1 + raw_dst[i] + 2]) = floatx2{rb[i].z, rb[i].w};
+        }
     }
     load_raw(min(2, nK - 1));
     __syncthreads();
@@ -343,6 +383,171 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     }
     }       // MODE == 0
 
+    // ---- MODE 3: fused, every wave owns all 36 components of 16 blocks x 16 channels (see the kernel's header)
+    if constexpr (MODE == 3) {
+        const int bh = wave & 1, cq = wave >> 1;          // half of the tile's blocks, quarter of the 64 channels
+        const int l16 = lane & 15, q = lane >> 4;
+        // Filter slab of MODE 3: [chunk][f2 = 0..17][cq][lane][4 floats] = components 2 f2, 2 f2 + 1 x input channels
+        // 2 q, 2 q + 1 of the chunk, for output channel 16 cq + lane % 16: one 16-byte load feeds four MFMAs.
+        const int w3_off = (cq * 64 + lane) * 16;
+        auto load_w3 = [&](int kc, int f2) {
+            return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w3_off, kc * (kWChunkFloats * 4) + f2 * 4096, 0));
+        };
+        float4 bw3[9];                                    // fragment ring: step s (two components) sits in slot s % 9, reloaded 9 steps ahead
+        {
+            float4 rb[NRAW];                             // raw tiles 0 and 1 requested together: one memory round trip
+            load_raw(0);
+#pragma unroll
+            for (int i = 0; i < NRAW; ++i)
+                rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, raw_src[i], kCK * 4, 0));
+#pragma unroll
+            for (int f = 0; f < 9; ++f) bw3[f] = load_w3(0, f);
+            store_raw(kR0);
+#pragma unroll
+            for (int i = 0; i < NRAW; ++i) {
+            *reinterpret_cast<floatx2*>(&lds[kR1 + raw_dst[i]]) = floatx2{rb[i].x, rb[i].y};
+            *reinterpret_cast<floatx2*>(&lds[kR1 + raw_dst[i] + 2]) = floatx2{rb[i].z, rb[i].w};
+        }
+        }
+        load_raw(min(2, nK - 1));
+        __syncthreads();
+        transform(kR0, 0);
+        __syncthreads();
+
+        // operands of a lane within a component pair of U: block 16 bh + lane % 16, channels 2 q and 2 q + 1 of both
+        // components (k of the two MFMAs that consume the chunk's 8 channels: k = lane / 16, channel = 2 k + step)
+        const int u3 = (16 * bh + l16) * (2 * kCK) + 4 * q;
+        auto chunk3 = [&](int kc, auto parity) {
+            constexpr int P = decltype(parity)::value;
+            constexpr int ucur = P * kUFloats, unxt = (1 - P) * kUFloats;
+            constexpr int rnxt = kR0 + (1 - P) * kRBuf, rfill = kR0 + P * kRBuf;
+            const int kn = min(kc + 1, nK - 1);
+            if (kc + 1 < nK) {                          // uniform
+                transform(rnxt, unxt);
+                store_raw(rfill);
+                load_raw(min(kc + 3, nK - 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* ub = &lds[ucur + u3];
+            float4 a4[2][2];                            // operands of a group of 4 components, read one group ahead
+#pragma unroll
+            for (int c = 0; c < 2; ++c) a4[0][c] = *reinterpret_cast<const float4*>(ub + c * (2 * kUC));
+#pragma unroll
+            for (int g = 0; g < 9; ++g) {
+                if (g + 1 < 9) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) a4[(g + 1) & 1][c] = *reinterpret_cast<const float4*>(ub + (2 * (g + 1) + c) * (2 * kUC));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const floatx2 av[4] = {floatx2{a4[g & 1][0].x, a4[g & 1][0].y}, floatx2{a4[g & 1][0].z, a4[g & 1][0].w},
+                                       floatx2{a4[g & 1][1].x, a4[g & 1][1].y}, floatx2{a4[g & 1][1].z, a4[g & 1][1].w}};
+                const float4 b0 = bw3[(2 * g) % 9], b1 = bw3[(2 * g + 1) % 9];
+                // the two MFMAs of a component (its 8 channels) sit four instructions apart
+                acc3[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].x, b0.x, acc3[4 * g + 0], 0, 0, 0);
+                acc3[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].x, b0.z, acc3[4 * g + 1], 0, 0, 0);
+                acc3[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2].x, b1.x, acc3[4 * g + 2], 0, 0, 0);
+                acc3[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3].x, b1.z, acc3[4 * g + 3], 0, 0, 0);
+                acc3[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].y, b0.y, acc3[4 * g + 0], 0, 0, 0);
+                acc3[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].y, b0.w, acc3[4 * g + 1], 0, 0, 0);
+                acc3[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2].y, b1.y, acc3[4 * g + 2], 0, 0, 0);
+                acc3[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3].y, b1.w, acc3[4 * g + 3], 0, 0, 0);
+                // the two slots just used: refilled with the fragments nine steps on (this chunk's second half, or the
+                // next chunk's first half)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int st = 2 * g + d + 9;
+                    bw3[(2 * g + d) % 9] = (st < 18) ? load_w3(kc, st) : load_w3(kn, st - 18);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        for (int kc = 0; kc < nK; kc += 2) {          // nK is even
+            chunk3(kc, std::integral_constant<int, 0>{});
+            chunk3(kc + 1, std::integral_constant<int, 1>{});
+        }
+
+        // ---- epilogue: Y = A^T M A per (block, channel) in registers, max-pool in registers, the (pooled) tile staged in
+        // LDS once (every wave has passed the loop's last barrier: the loop's buffers are free), one barrier, 16-byte stores.
+        // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].
+        constexpr int PW = (POOL == 1) ? 2 : 4, PH = (POOL == 0) ? 4 : 2;      // outputs a block keeps after pooling
+        constexpr int kTW = 8 * PW, kTH = 4 * PH;                              // the tile after pooling
+        auto at4 = [](float m0, float m1, float m2, float m3, float m4, float m5, float (&o)[4]) {
+            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+            o[0] = (m0 + s1) + s2;
+            o[1] = d1 + 2.0f * d2;
+            o[2] = s1 + 4.0f * s2;
+            o[3] = (d1 + 8.0f * d2) + m5;
+        };
+        const int ch3 = cq * 16 + l16;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int m = 16 * bh + 4 * q + v, by = m >> 3, bx = m & 7;
+            float Wt[6][4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                at4(acc3[i * 6 + 0][v], acc3[i * 6 + 1][v], acc3[i * 6 + 2][v], acc3[i * 6 + 3][v], acc3[i * 6 + 4][v], acc3[i * 6 + 5][v], Wt[i]);
+            float Y[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float col[4];
+                at4(Wt[0][c], Wt[1][c], Wt[2][c], Wt[3][c], Wt[4][c], Wt[5][c], col);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Y[r][c] = col[r];
+            }
+            // the four lane groups of a wave (q) write pixels a multiple of 64 floats apart: each rotates its 64 channels
+            // by a different quarter so that they use different LDS banks
+            const int pos = (ch3 + 16 * ((bx >> 2) & 1) + 32 * (by & 1)) & 63;
+            float* O = &lds[((by * PH) * kTW + bx * PW) * kOS + pos];
+#pragma unroll
+            for (int r = 0; r < PH; ++r)
+#pragma unroll
+                for (int c = 0; c < PW; ++c) {
+                    float o;
+                    if (POOL == 0) o = Y[r][c];
+                    else if (POOL == 1) o = fmaxf(fmaxf(Y[2 * r][2 * c], Y[2 * r][2 * c + 1]), fmaxf(Y[2 * r + 1][2 * c], Y[2 * r + 1][2 * c + 1]));
+                    else o = fmaxf(Y[2 * r][c], Y[2 * r + 1][c]);
+                    O[(r * kTW + c) * kOS] = o;
+                }
+        }
+        __syncthreads();
+        const bool vec3 = (a.cout & 3) == 0 && co0 + 3 < a.cout;
+        const int Ho3 = (POOL == 0) ? a.H : a.H / 2, Wo3 = (POOL == 1) ? a.W / 2 : a.W;
+        const int ox0 = (POOL == 1) ? (x0 >> 1) : x0;
+#pragma unroll 4
+        for (int it = 0; it < kTW * kTH / 32; ++it) {
+            const int px = (tid >> 4) + it * 32;
+            const int py = px / kTW, pxx = px % kTW;
+            const int by = py / PH, bx = pxx / PW;
+            const int ob = pair ? 2 * b + (by >> 1) : b;                   // image of this block row
+            const int yy = (pair ? (by & 1) * PH : ((POOL == 0) ? y0 : (y0 >> 1)) + by * PH) + py % PH, xx = ox0 + pxx;
+            if (ob >= a.B || yy >= Ho3 || xx >= Wo3) continue;
+            const int rot = 16 * ((bx >> 2) & 1) + 32 * (by & 1);
+            floatx4 val = *reinterpret_cast<const floatx4*>(&lds[px * kOS + ((c4 * 4 + rot) & 63)]) + bias4;
+            const int64_t idx = (((int64_t)ob * Ho3 + yy) * Wo3 + xx) * a.cout + co0;
+            if (vec3) {
+                if (POOL == 0 && a.res) val += *reinterpret_cast<const floatx4*>(a.res + idx);
+                if (a.relu) {
+                    val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
+                }
+                *reinterpret_cast<floatx4*>(a.y + idx) = val;
+            } else {
+                const float e[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (co0 + k < a.cout) {
+                        float o1 = e[k];
+                        if (POOL == 0 && a.res) o1 += a.res[idx + k];
+                        if (a.relu) o1 = fmaxf(o1, 0.0f);
+                        a.y[idx + k] = o1;
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    if constexpr (MODE != 3) {
     // ---- inverse transform and output, one block row (4 x 32 outputs) at a time.  Register v of a lane belongs to block
     // m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5), i.e. block row v >> 2, and to output channel lane & 31 of the wave's 32.
     // The wave's 3x3 components contribute
@@ -431,6 +636,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
             }
         }
     }
+    }       // MODE != 3
 }
 
 }  // namespace
@@ -461,6 +667,25 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
         }
     OCR_TRY(L.w_wino4.reserve(w.size() * sizeof(float)));
     OCR_HIP_CHECK(hipMemcpy(L.w_wino4.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (cin < kSplitMinCin) {
+        // the same transformed filters in the layout of MODE 3 (shallow layers):
+        // [n block][k chunk][f2 = f / 2][cq][lane = 16 q + j][t = 2 (f % 2) + step]: output channel 64 nblock + 16 cq + j,
+        // input channel 8 kchunk + 2 q + step
+        std::vector<float> w3((size_t)nN * nK * kWChunkFloats, 0.0f);
+        for (int o = 0; o < cout; ++o)
+            for (int c = 0; c < cin; ++c) {
+                const int nbk = o / 64, cq = (o % 64) / 16, j = o % 16;
+                const int kc = c / kCK, q = (c % kCK) / 2, step = c % 2;
+                const int chalf = (o % 64) / 32, j32 = o % 32, hh = (c % kCK) / 4, t = c % 4;
+                for (int f = 0; f < 36; ++f) {
+                    const size_t src = ((((((size_t)(nbk * nK + kc) * 36 + f) * 2 + chalf) * 2 + hh) * 32 + j32) * 4) + t;
+                    const size_t dst = (((((size_t)(nbk * nK + kc) * 18 + f / 2) * 4 + cq) * 64 + (16 * q + j)) * 4) + 2 * (f % 2) + step;
+                    w3[dst] = w[src];
+                }
+            }
+        OCR_TRY(L.w_wino4b.reserve(w3.size() * sizeof(float)));
+        OCR_HIP_CHECK(hipMemcpy(L.w_wino4b.ptr, w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return OCRHIP_OK;
 }
 
@@ -497,7 +722,7 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     OCR_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lds_opt_in_lock(lds_opt_in_mutex);
     bool& lds_opt_in = lds_opt_in_dev[dev & 63];
-#define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2)
+#define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2) X(0, 3) X(1, 3) X(2, 3)
     if (!lds_opt_in) {
 #define OCR_W4_OPT_IN(P, M)                                                                                               \
     OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<P, M>),                       \
@@ -512,9 +737,12 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     const int64_t tiles_total = (int64_t)a.tiles_per_image * (a.pair ? (B + 1) / 2 : B);
     const int64_t v_bytes = tiles_total * nK * kUFloats * 4;
     int mode = 0;
-    static const int split_min_cin = getenv("OCRHIP_SPLIT_MIN_CIN") ? atoi(getenv("OCRHIP_SPLIT_MIN_CIN")) : 256;      // development aid
-    if (ws && wino4_split() && L.cin >= split_min_cin && v_bytes <= (6ll << 30) && ws->reserve((size_t)v_bytes) == OCRHIP_OK) mode = 2;
-    a.v = mode ? ws->as<float>() : nullptr;
+    if (ws && wino4_split() && L.cin >= kSplitMinCin && v_bytes <= (6ll << 30) && ws->reserve((size_t)v_bytes) == OCRHIP_OK) mode = 2;
+    if (mode == 0 && L.w_wino4b.ptr && wino4_wave_tiles()) {      // shallow layer: every wave owns whole (block, channel) tiles
+        mode = 3;
+        a.w = L.w_wino4b.as<float>();
+    }
+    a.v = mode == 2 ? ws->as<float>() : nullptr;
     a.chunks_per_group = 8;
     const double out_px = (double)B * H * W;
     const double out_elems = out_px * L.cout / (pool == 1 ? 4.0 : (pool == 2 ? 2.0 : 1.0));
@@ -530,9 +758,9 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     char pname[64];
     static const bool per_layer = getenv("OCRHIP_PROFILE_LAYERS") != nullptr;      // development aid: one profile line per layer shape
     if (per_layer)
-        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<p%d,c%d-%d,h%d>", mode == 2 ? "_mul" : "", pool, L.cin, L.cout, H);
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<p%d,c%d-%d,h%d>", mode == 2 ? "_mul" : (mode == 3 ? "_w" : ""), pool, L.cin, L.cout, H);
     else
-        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<n64,pool%d,tile16x32>", mode == 2 ? "_mul" : "", pool);
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<n64,pool%d,tile16x32>", mode == 2 ? "_mul" : (mode == 3 ? "_w" : ""), pool);
     ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
                    4.0 * ((mode == 2 ? 0.0 : out_px * L.cin) + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout) + (mode == 2 ? (double)v_bytes : 0.0), s);
 #define OCR_W4_LAUNCH(P, M)                                                                                               \
