@@ -75,7 +75,7 @@ int ocrhip_destroy(ocrhip_handle h);
  *   ocrhip_check_errors / the next ocrhip_crnn_forward* call on the handle (OCRHIP_EHIP, "lstm hand-over timed out").
  *   "lstm_debug_drop_handover": test hook, 0 (default) | 1: one workgroup of the persistent recurrence withholds its
  *   first hand-over and waits give up after 4096 spins, which exercises the time-out path above.
- *   "wino4_split": 1 (default) runs the F(4x4,3x3) layers with >= 256 input channels as two kernels (transform the
+ *   "wino4_split": 1 (default) runs the F(4x4,3x3) layers with >= 512 input channels as two kernels (transform the
  *   input tiles once into a workspace, then multiply from it); 0 keeps them fused (every 64-channel workgroup transforms
  *   its tile itself).  Same arithmetic, identical results.
  *   "wino4_wave_tiles": 1 (default): the fused F(4x4,3x3) launches (fewer than 256 input channels) give every wave whole

@@ -54,7 +54,8 @@ constexpr int kPartFloats = 128 * kOS;          // one wave group's share of a b
 constexpr int kStageFloats = 4 * kPartFloats;
 constexpr int kLdsBytes = 4 * (kLoopFloats > kStageFloats ? kLoopFloats : kStageFloats);
 constexpr int kWChunkFloats = 36 * 2 * 64 * 4;  // transformed filters of one chunk of one 64-channel block
-constexpr int kSplitMinCin = 256;               // layers at least this deep run as transform kernel + multiply kernel
+constexpr int kSplitMinCin = 512;               // layers at least this deep run as transform kernel + multiply kernel
+constexpr int kWaveTileMaxCin = 256;            // fused layers shallower than this run MODE 3 (few chunks: the cheap epilogue pays), the others MODE 0 (half the operand loads per MFMA)
 
 struct Wino4Args {
     const float* x;        // (B,H,W,cin)
@@ -101,7 +102,7 @@ __device__ __forceinline__ void inverse_part(const float (&M)[3][3], float (&Y)[
     }
 }
 
-// MODE 0: the fused kernel described above.  MODE 1 and 2 split it for deep layers (>= 256 input channels), where the
+// MODE 0: the fused kernel described above.  MODE 1 and 2 split it for deep layers (>= 512 input channels), where the
 // data transform - repeated by each of the Cout / 64 workgroups of a tile and paid for in MFMA issue time - weighs
 // more than writing the transformed tile to memory once:
 //   MODE 1 transforms only: a workgroup owns a tile and a group of chunks (the `channel block` index of the grid) and
@@ -667,7 +668,7 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
         }
     OCR_TRY(L.w_wino4.reserve(w.size() * sizeof(float)));
     OCR_HIP_CHECK(hipMemcpy(L.w_wino4.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (cin < kSplitMinCin) {
+    if (cin < kWaveTileMaxCin) {
         // the same transformed filters in the layout of MODE 3 (shallow layers):
         // [n block][k chunk][f2 = f / 2][cq][lane = 16 q + j][t = 2 (f % 2) + step]: output channel 64 nblock + 16 cq + j,
         // input channel 8 kchunk + 2 q + step
