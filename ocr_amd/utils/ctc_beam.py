@@ -4,9 +4,11 @@ Stands in for `ctc_decode(method='beam_search')` of the reference (utils/text/ct
 `keras.ops.ctc_decode(strategy='beam_search')`, which on TensorFlow is `tf.nn.ctc_beam_search_decoder`
 over the log-softmax of the logits).  Keras is not available to compare against, so this follows
 the published algorithm (Graves' prefix search with blank / non-blank path probabilities in log
-space); two deliberate simplifications: only the `num_beams` most probable labels of a time step
-(plus the blank) are expanded, and only the best sequence is returned.  The score is the log
-probability of the sequence divided by the input length, like the reference's wrapper returns.
+space): at every step EVERY label extends every kept prefix and the `num_beams` most probable prefixes
+survive (no pruning of the labels of a step; the expansion is vectorised over the vocabulary and only the
+extensions that can reach the beam, or that merge into a kept prefix, are materialised).  Only the best
+sequence is returned.  The score is the log probability of the sequence divided by the input length, like
+the reference's wrapper returns.
 
 This is the compatibility path for `BaseOCR.infer(method='beam_search')` (the reference's default);
 the fast path of this package is greedy decoding on the GPU.
@@ -32,28 +34,39 @@ def ctc_beam_search_one(logits, num_beams=10, blank=0):
     m = logits.max(axis=1, keepdims=True)
     logp = logits - (m + np.log(np.exp(logits - m).sum(axis=1, keepdims=True)))
     beams = {(): (0.0, _NEG)}                     # prefix -> (log p ending in blank, log p ending in non-blank)
-    k_sym = min(V, num_beams + 1)
     for t in range(T):
         row = logp[t]
-        cand = np.argpartition(-row, k_sym - 1)[:k_sym] if k_sym < V else np.arange(V)
-        cand = [int(c) for c in cand if c != blank]
+        prefixes = list(beams)
+        pb = np.array([beams[p][0] for p in prefixes])
+        pnb = np.array([beams[p][1] for p in prefixes])
+        total = np.logaddexp(pb, pnb)
+        # log p of every extension (prefix n, label c): any path into the prefix, except that a repeat of the prefix's
+        # last label needs a blank in between
+        ext = total[:, None] + row[None, :]
+        for n, p in enumerate(prefixes):
+            if p:
+                ext[n, p[-1]] = pb[n] + row[p[-1]]
+        ext[:, blank] = _NEG
+        # the extensions worth a dictionary entry: the num_beams most probable ones, and those that land on a kept prefix
+        # (their probability adds to what that prefix keeps by staying)
+        flat = ext.ravel()
+        k = min(num_beams, flat.size)
+        picked = set(int(i) for i in np.argpartition(-flat, k - 1)[:k])
+        index = {p: n for n, p in enumerate(prefixes)}
+        for p in prefixes:
+            if p and p[:-1] in index:
+                picked.add(index[p[:-1]] * V + p[-1])
         nxt = {}
-        for prefix, (pb, pnb) in beams.items():
-            total = _logaddexp(pb, pnb)
+        for n, p in enumerate(prefixes):
             # stay on the prefix: a blank, or a repeat of its last label
-            b0, nb0 = nxt.get(prefix, (_NEG, _NEG))
-            b0 = _logaddexp(b0, total + row[blank])
-            if prefix:
-                nb0 = _logaddexp(nb0, pnb + row[prefix[-1]])
-            nxt[prefix] = (b0, nb0)
-            for c in cand:
-                ext = prefix + (c,)
-                b1, nb1 = nxt.get(ext, (_NEG, _NEG))
-                if prefix and c == prefix[-1]:
-                    nb1 = _logaddexp(nb1, pb + row[c])        # a repeat needs a blank in between
-                else:
-                    nb1 = _logaddexp(nb1, total + row[c])
-                nxt[ext] = (b1, nb1)
+            nxt[p] = (total[n] + row[blank], pnb[n] + row[p[-1]] if p else _NEG)
+        for i in picked:
+            n, c = divmod(i, V)
+            if flat[i] == _NEG:
+                continue
+            q = prefixes[n] + (c,)
+            b1, nb1 = nxt.get(q, (_NEG, _NEG))
+            nxt[q] = (b1, _logaddexp(nb1, flat[i]))
         best = sorted(nxt.items(), key=lambda kv: -_logaddexp(kv[1][0], kv[1][1]))[:num_beams]
         beams = dict(best)
     prefix, (pb, pnb) = max(beams.items(), key=lambda kv: _logaddexp(kv[1][0], kv[1][1]))
