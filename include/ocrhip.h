@@ -40,7 +40,10 @@ enum {
 };
 
 enum { OCRHIP_F32 = 0, OCRHIP_BF16 = 1, OCRHIP_U8 = 2 };
-enum { OCRHIP_MERGE_UNION = 0, OCRHIP_MERGE_AVERAGE = 1 };
+/* UNION and AVERAGE are the reference's merge methods (locality_aware_nms.py:99-126).  WEIGHTED is an opt-in extension
+ * with no counterpart there: the score-weighted merge of the original EAST LANMS inside the reference's iteration (a
+ * box becomes the mean of itself and the boxes it absorbs, weighted by score, and takes over their weights). */
+enum { OCRHIP_MERGE_UNION = 0, OCRHIP_MERGE_AVERAGE = 1, OCRHIP_MERGE_WEIGHTED = 2 };
 
 /* A named host tensor handed to *_load_weights.  Names and layouts are those of the original
  * torch checkpoints the reference converts from (models/weights_converter.py:252-322):

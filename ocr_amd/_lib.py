@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, 'libocrhip.so')
 
 OCRHIP_OK, OCRHIP_EINVAL, OCRHIP_ECAP, OCRHIP_EHIP, OCRHIP_ESTATE = 0, -1, -2, -3, -4
 F32, BF16, U8 = 0, 1, 2
-MERGE_UNION, MERGE_AVERAGE = 0, 1
+MERGE_UNION, MERGE_AVERAGE, MERGE_WEIGHTED = 0, 1, 2
 
 c_int, c_float, c_void_p, c_char_p, c_int64 = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p,
                                                 ctypes.c_int64)

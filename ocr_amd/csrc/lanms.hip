@@ -49,6 +49,8 @@ struct Image {
     float4* bounds;       // per 64-entry tile of act: (min x1, min y1, max x2, max y2)
     int* kept;            // indices of the kept boxes
     int* hdr;             // [0] = loop condition published by the split first iteration
+    float* wcur;          // weighted merge: weight of every box (its score plus the weights of what it absorbed)
+    float* wnxt;
 };
 
 __device__ __forceinline__ unsigned order_key(float s) {
@@ -119,8 +121,11 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
 
         bool has_upper = false, has_lower = false, hit_by_clean = false;
         float mnx = INFINITY, mny = INFINITY, mxx = 0.f, mxy = 0.f;     // union accumulators
-        float sx1 = 0.f, sy1 = 0.f, sx2 = 0.f, sy2 = 0.f;               // average accumulators
+        float sx1 = 0.f, sy1 = 0.f, sx2 = 0.f, sy2 = 0.f;               // average / weighted accumulators
+        float sw = 0.f;                                                  // weighted: sum of the absorbed weights
         int n_merged = 0;
+        const bool weighted = MODE == 1 && merge_method == OCRHIP_MERGE_WEIGHTED;
+        const float w_t = (weighted && t_valid) ? im.wcur[t] : 0.f;
 
         for (int S0 = 0; S0 < ntiles; S0 += 64) {
             unsigned long long cand;
@@ -144,6 +149,7 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
                 const unsigned key_l = u_valid ? im.key[u_l] : 0u;
                 const unsigned fl_l = u_valid ? im.flags[u_l] : 0u;
                 const float area_l = box_area(bu_l);
+                const float w_l = (weighted && u_valid) ? im.wcur[u_l] : 0.f;
                 for (int k = 0; k < cnt; ++k) {
                     const float ux1 = bcast(bu_l.x, k), uy1 = bcast(bu_l.y, k);
                     const float ux2 = bcast(bu_l.z, k), uy2 = bcast(bu_l.w, k);
@@ -168,9 +174,15 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
                     } else if (MODE == 1) {
                         hit_by_clean |= hit && u_better && !(fl_u & kHasUpper);
                         if (hit && t_better && !(fl_t & kHasUpper)) {
-                            mnx = fminf(mnx, ux1); mny = fminf(mny, uy1);
-                            mxx = fmaxf(mxx, ux2); mxy = fmaxf(mxy, uy2);
-                            sx1 = sx1 + ux1; sy1 = sy1 + uy1; sx2 = sx2 + ux2; sy2 = sy2 + uy2;
+                            if (weighted) {
+                                const float w_u = bcast(w_l, k);
+                                sx1 = sx1 + w_u * ux1; sy1 = sy1 + w_u * uy1; sx2 = sx2 + w_u * ux2; sy2 = sy2 + w_u * uy2;
+                                sw = sw + w_u;
+                            } else {
+                                mnx = fminf(mnx, ux1); mny = fminf(mny, uy1);
+                                mxx = fmaxf(mxx, ux2); mxy = fmaxf(mxy, uy2);
+                                sx1 = sx1 + ux1; sy1 = sy1 + uy1; sx2 = sx2 + ux2; sy2 = sy2 + uy2;
+                            }
                             n_merged++;
                         }
                     } else if (MODE == 2) {
@@ -188,8 +200,15 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
                           (has_lower ? kHasLower : 0u);
         } else if (MODE == 1) {
             float4 nb;
+            float w_new = w_t;
             if (merge_method == OCRHIP_MERGE_UNION) {
                 nb = make_float4(fminf(bt.x, mnx), fminf(bt.y, mny), fmaxf(bt.z, mxx), fmaxf(bt.w, mxy));
+            } else if (weighted) {
+                // score-weighted mean of the box and what it absorbs; a box that absorbs nothing stays bit for bit
+                w_new = w_t + sw;
+                nb = (n_merged == 0) ? bt
+                                     : make_float4((w_t * bt.x + sx1) / w_new, (w_t * bt.y + sy1) / w_new,
+                                                   (w_t * bt.z + sx2) / w_new, (w_t * bt.w + sy2) / w_new);
             } else {
                 const float cntf = (float)(1 + n_merged);
                 nb = make_float4((bt.x + sx1) / cntf, (bt.y + sy1) / cntf, (bt.z + sx2) / cntf, (bt.w + sy2) / cntf);
@@ -198,7 +217,9 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
                 nb = make_float4(0.f, 0.f, 0.f, 0.f);
                 im.flags[t] = fl_t | kSupp;
                 if (fl_t & kHasLower) *cond = 1;
+                w_new = 0.f;
             }
+            if (weighted) im.wnxt[t] = w_new;
             im.nxt[t] = nb;
         } else if (MODE == 2) {
             im.flags[t] = (fl_t & ~(kHasUpper | kKill)) | (has_upper ? kHasUpper : 0u);
@@ -302,7 +323,9 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
         im.flags = reinterpret_cast<unsigned*>(w);             w += c * sizeof(unsigned);
         im.act = reinterpret_cast<int*>(w);                    w += c * sizeof(int);
         im.act2 = reinterpret_cast<int*>(w);                   w += c * sizeof(int);
-        im.kept = reinterpret_cast<int*>(w);
+        im.kept = reinterpret_cast<int*>(w);                   w += c * sizeof(int);
+        im.wcur = reinterpret_cast<float*>(w);                 w += c * sizeof(float);
+        im.wnxt = reinterpret_cast<float*>(w);
     }
 
     const bool cull_merge = p.merge_thr > 0.f;
@@ -322,6 +345,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
         im.cur[t] = bx;
         im.nxt[t] = bx;
         im.key[t] = p.scores ? order_key(p.scores[o + t]) : 0u;
+        if (p.merge_method == OCRHIP_MERGE_WEIGHTED) im.wcur[t] = im.wnxt[t] = p.scores ? p.scores[o + t] : 1.0f;
         im.flags[t] = 0u;
         im.act[t] = t;
     }
@@ -399,6 +423,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
         }
         // cur <-> nxt; suppressed boxes leave the active list (they are all-zero from now on)
         float4* tmp = im.cur; im.cur = im.nxt; im.nxt = tmp;
+        float* tw = im.wcur; im.wcur = im.wnxt; im.wnxt = tw;
         if (cull_merge) {
             n_act = compact(im, im.act, im.act2, n_act, kSupp, true, s_wave, &s_base);
             int* ta = im.act; im.act = im.act2; im.act2 = ta;
@@ -510,7 +535,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
 
 size_t ws_bytes_per_image(int cap) {
     const size_t c = (size_t)cap;
-    size_t bytes = 64 + 2 * c * sizeof(float4) + ((c + 63) / 64) * sizeof(float4) + 5 * c * sizeof(int);
+    size_t bytes = 64 + 2 * c * sizeof(float4) + ((c + 63) / 64) * sizeof(float4) + 7 * c * sizeof(int);
     return (bytes + 255) & ~(size_t)255;
 }
 
@@ -525,7 +550,7 @@ int launch_lanms(ocrhip_ctx* h, const float* xyxy, const float* scores, const in
     // With a threshold <= 0 the reference's masked-matrix expressions degenerate (every entry of
     // `iou * mask >= thr` is true, diagonal and lower triangle included); not supported.
     OCR_REQUIRE(merge_thr > 0.f && nms_thr > 0.f, "lanms: thresholds must be > 0 (merge %g, nms %g)", merge_thr, nms_thr);
-    OCR_REQUIRE(merge_method == OCRHIP_MERGE_UNION || merge_method == OCRHIP_MERGE_AVERAGE,
+    OCR_REQUIRE(merge_method == OCRHIP_MERGE_UNION || merge_method == OCRHIP_MERGE_AVERAGE || merge_method == OCRHIP_MERGE_WEIGHTED,
                 "lanms: unknown merge method %d", merge_method);
     OCR_REQUIRE((reinterpret_cast<uintptr_t>(xyxy) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_boxes) & 15) == 0 &&
                     (merged == nullptr || (reinterpret_cast<uintptr_t>(merged) & 15) == 0),

@@ -9,9 +9,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, U8, MERGE_UNION, MERGE_AVERAGE, TensorDesc, check
+from ._lib import F32, BF16, U8, MERGE_UNION, MERGE_AVERAGE, MERGE_WEIGHTED, TensorDesc, check
 
-_MERGE = {'union': MERGE_UNION, 'average': MERGE_AVERAGE}
+_MERGE = {'union': MERGE_UNION, 'average': MERGE_AVERAGE, 'weighted': MERGE_WEIGHTED}
 
 
 def _ptr(t):

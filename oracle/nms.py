@@ -39,28 +39,47 @@ def _merge_boxes(boxes, box_slice, mask, merge_method):
     raise ValueError(merge_method)
 
 
-def self_merging_step(boxes, tri, merge_threshold, merge_method):
-    """One iteration of `_self_merging_body` (locality_aware_nms.py:74-97)."""
+def self_merging_step(boxes, tri, merge_threshold, merge_method, weights=None):
+    """One iteration of `_self_merging_body` (locality_aware_nms.py:74-97).
+
+    merge_method 'weighted' is NOT in the reference (an opt-in extension: the score-weighted merge of the original
+    EAST LANMS inside the reference's iteration): box i becomes the mean of itself and the boxes it absorbs weighted by
+    `weights`, and takes over their weights; a box that absorbs nothing is unchanged.  Returns the new weights as a
+    third value in that mode."""
     iou = compute_iou(boxes, as_matrix=True)
     iou = iou * (tri & (iou >= merge_threshold)).astype(iou.dtype)
     can_suppress_others = (np.max(iou, axis=0) < merge_threshold).astype(iou.dtype)[:, None]
     merging_mask = iou * can_suppress_others >= merge_threshold
     suppressed_box = np.any(merging_mask, axis=0)[:, None]
+    cond = bool(np.any(iou * suppressed_box.astype(iou.dtype) >= merge_threshold))
+    if merge_method == 'weighted':
+        w = weights.astype(np.float64)
+        m = merging_mask.astype(np.float64)
+        sw = m @ w
+        num = w[:, None] * boxes.astype(np.float64) + m @ (w[:, None] * boxes.astype(np.float64))
+        den = np.where(sw > 0, w + sw, 1.0)
+        merged = np.where((sw > 0)[:, None], num / den[:, None], boxes.astype(np.float64)).astype(np.float32)
+        keep = np.logical_not(suppressed_box)
+        return merged * keep.astype(merged.dtype), cond, ((w + sw) * keep[:, 0]).astype(np.float32)
     merged = _merge_boxes(boxes, boxes, merging_mask, merge_method)
     merged = merged * np.logical_not(suppressed_box).astype(merged.dtype)
-    cond = bool(np.any(iou * suppressed_box.astype(iou.dtype) >= merge_threshold))
     return merged, cond
 
 
-def self_merging(boxes, merge_threshold, merge_method='union', max_iter=None):
+def self_merging(boxes, merge_threshold, merge_method='union', max_iter=None, weights=None):
     n = len(boxes)
     if max_iter is None:
         max_iter = n
     idx = np.arange(n)
     tri = idx[None, :] > idx[:, None]
     cond, it = True, 0
+    if merge_method == 'weighted':
+        weights = np.ones(n, np.float32) if weights is None else np.asarray(weights, dtype=np.float32)
     while cond and it < max_iter:
-        boxes, cond = self_merging_step(boxes, tri, merge_threshold, merge_method)
+        if merge_method == 'weighted':
+            boxes, cond, weights = self_merging_step(boxes, tri, merge_threshold, merge_method, weights)
+        else:
+            boxes, cond = self_merging_step(boxes, tri, merge_threshold, merge_method)
         it += 1
     return boxes, it
 
@@ -116,7 +135,7 @@ def lanms(boxes, scores=None, max_output_size=None, nms_threshold=0.25, *,
         return boxes, scores, np.zeros((0,), dtype=bool), order, 0
     nms_threshold = np.float32(nms_threshold)
     merge_threshold = np.float32(merge_threshold)
-    boxes, n_iter = self_merging(boxes, merge_threshold, merge_method, max_iter)
+    boxes, n_iter = self_merging(boxes, merge_threshold, merge_method, max_iter, weights=scores)
     mask = np.any(boxes > 0, axis=1)
     if nms_threshold < merge_threshold:
         mask = mask & fast_nms(boxes, None, max_output_size, nms_threshold)[2]

@@ -172,6 +172,30 @@ def test_lanms_random_boxes_match_oracle(ctx):
             _compare_with_oracle(got, b, bl[b], sl[b], onms.lanms, exact=(method == 'union'), **kw)
 
 
+def test_lanms_weighted_merge_extension(ctx):
+    """merge_method='weighted' (not in the reference: the score-weighted merge of the original EAST LANMS inside the
+    reference's iteration): a hand-computed case, and random sets against the oracle's float64 statement of it."""
+    b = np.array([[0.10, 0.10, 0.50, 0.30], [0.12, 0.10, 0.54, 0.30], [0.70, 0.70, 0.90, 0.80]], np.float32)
+    s = np.array([0.9, 0.3, 0.5], np.float32)
+    got = _gpu_lanms(ctx, [b], [s], merge_threshold=0.3, nms_threshold=0.2, merge_method='weighted')
+    assert int(got['counts'][0]) == 2
+    want = (0.9 * b[0].astype(np.float64) + 0.3 * b[1].astype(np.float64)) / 1.2
+    np.testing.assert_allclose(got['boxes'][0, 0], want, rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(got['boxes'][0, 1], b[2])               # a box that absorbs nothing stays bit for bit
+    rng = np.random.default_rng(12)
+    for trial in range(10):
+        bl, sl = [], []
+        for _ in range(3):
+            n = int(rng.integers(1, 150))
+            xy = rng.uniform(0, 0.8, (n, 2)).astype(np.float32)
+            bl.append(np.concatenate([xy, xy + rng.uniform(0.02, 0.3, (n, 2)).astype(np.float32)], 1))
+            sl.append(rng.permutation(n).astype(np.float32) / max(n, 1) * 0.6 + 0.36)
+        kw = dict(merge_threshold=float(rng.choice([0.3, 0.5])), nms_threshold=float(rng.choice([0.2, 0.6])), merge_method='weighted')
+        got = _gpu_lanms(ctx, bl, sl, **kw)
+        for i in range(3):
+            _compare_with_oracle(got, i, bl[i], sl[i], onms.lanms, exact=False, **kw)
+
+
 def test_lanms_score_ties_use_input_order(ctx):
     rng = np.random.default_rng(8)
     xy = rng.uniform(0, 0.8, (80, 2)).astype(np.float32)
