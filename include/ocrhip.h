@@ -114,6 +114,15 @@ int ocrhip_east_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n
 int ocrhip_image_resize_norm(ocrhip_handle h, const void* d_img, int in_dtype, int B, int H, int W, int out_h,
                              int out_w, float* d_out, ocrhip_stream stream);
 
+/* Dice coefficient of two score maps: replaces `dice_coeff(output, prev_output)` in the frame de-duplication of
+ * BaseOCR.stream_fn (models/ocr/base_ocr.py:402,408-411; utils/distances.py:125-130):
+ *   d_out[0] = 2 * sum(x * y) / (sum(x) + sum(y)), 0 when the denominator is 0; sums in float64.
+ *   d_x, d_y : device float32, n elements each taken every `stride` floats (stride 6 walks channel 0 of two
+ *              (mh,mw,6) detector maps in place)
+ *   d_out    : device float32[1] */
+int ocrhip_dice_coeff(ocrhip_handle h, const float* d_x, const float* d_y, int64_t n, int64_t stride, float* d_out,
+                      ocrhip_stream stream);
+
 /* EAST forward: replaces `compiled_infer(inputs)` in BaseDetector.infer
  * (models/detection/base_detector.py:72-76) and, for in_dtype == OCRHIP_U8, also the
  * `/255` + 'east' normalisation `(x - 0.5) / 0.5` (utils/image/image_normalization.py:57,

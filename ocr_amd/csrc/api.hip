@@ -449,6 +449,12 @@ int ocrhip_image_resize_norm(ocrhip_handle h, const void* d_img, int in_dtype, i
     return launch_resize_rgb_norm(d_img, in_dtype == OCRHIP_U8, B, H, W, out_h, out_w, d_out, (hipStream_t)stream);
 }
 
+int ocrhip_dice_coeff(ocrhip_handle h, const float* d_x, const float* d_y, int64_t n, int64_t stride, float* d_out,
+                      ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    return launch_dice_coeff(d_x, d_y, n, stride, d_out, (hipStream_t)stream);
+}
+
 int ocrhip_east_get_activation(ocrhip_handle h, const char* name, float* dst, int64_t dst_capacity, int64_t shape[4]) {
     OCR_HANDLE(h);
     return read_activation(h->east.taps, name, dst, dst_capacity, shape);

@@ -38,6 +38,7 @@ SOURCES = {
     'rnn.hip': [],
     'rnn_persistent.hip': [],
     'pool.hip': [],
+    'metrics.hip': ['-ffp-contract=off'],
 }
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 'ocrhip.h')]
 

@@ -247,6 +247,7 @@ int launch_pad_maxpool(const float* x, float* y, int B, int H, int W, int C, int
 
 // crop.hip: whole-page `/255` (uint8 only) -> antialiased stretch -> (x-0.5)/0.5, (B,H,W,3) -> float32 (B,oh,ow,3)
 int launch_resize_rgb_norm(const void* img, bool is_u8, int B, int H, int W, int oh, int ow, float* out, hipStream_t s);
+int launch_dice_coeff(const float* x, const float* y, int64_t n, int64_t stride, float* out, hipStream_t s);
 
 // rnn.hip
 int launch_mean_rows(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);

@@ -18,6 +18,21 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _uniform_stride(t):
+    """Element stride of a tensor whose elements lie at base + k * stride, k = 0..numel-1 in row-major order (a
+    contiguous tensor: 1; `m[..., 0]` of a contiguous (h,w,6) map: 6); None when there is no such stride."""
+    if t.numel() <= 1:
+        return 1
+    dims = [(n, st) for n, st in zip(t.shape, t.stride()) if n > 1]
+    step = dims[-1][1]
+    expect = step
+    for n, st in reversed(dims):
+        if st != expect:
+            return None
+        expect = st * n
+    return step if step >= 1 else None
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -115,6 +130,20 @@ class HipContext:
         check(self.lib.ocrhip_image_resize_norm(self._h, _ptr(images), in_dtype, B, H, W, int(out_h), int(out_w),
                                                 _ptr(out), _stream()))
         return out
+
+    def dice_coeff(self, x, y):
+        """Dice coefficient 2*sum(x*y) / (sum(x)+sum(y)) of two float32 GPU tensors of one shape (0 when both are all
+        zero) -> float32 GPU scalar.  Views that step over whole elements (`maps[..., 0]` of a contiguous map) are
+        walked in place."""
+        assert x.is_cuda and y.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32
+        if tuple(x.shape) != tuple(y.shape):
+            raise ValueError('dice_coeff: shapes differ: {} vs {}'.format(tuple(x.shape), tuple(y.shape)))
+        stride = _uniform_stride(x)
+        if stride is None or _uniform_stride(y) != stride:
+            x, y, stride = x.contiguous(), y.contiguous(), 1
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+        check(self.lib.ocrhip_dice_coeff(self._h, _ptr(x), _ptr(y), x.numel(), stride, _ptr(out), _stream()))
+        return out[0]
 
     def east_forward(self, images, compute_dtype=F32):
         """images: (B,H,W,3) uint8 raw or float32 normalised, on the GPU -> (B,H/4,W/4,6) float32."""

@@ -81,8 +81,9 @@ class EAST:
         return self.ctx.image_resize_norm(x[None].contiguous(), oh, ow)[0]
 
     # ---- inference ---------------------------------------------------------------------------
-    def infer(self, image, *, predicted=None, overwrite=False, **kwargs):
-        """base_detector.py:51-81: returns dict(filename, boxes, image, output)."""
+    def infer(self, image, *, predicted=None, overwrite=False, output_on_device=False, **kwargs):
+        """base_detector.py:51-81: returns dict(filename, boxes, image, output).  `output` is the (mh,mw,6) map as a
+        NumPy array, or the GPU tensor itself with `output_on_device` (what the stream's frame comparison reads)."""
         if predicted and not overwrite and isinstance(image, str) and image in predicted:
             return predicted[image]
         infos = image.copy() if isinstance(image, dict) else {}
@@ -92,7 +93,8 @@ class EAST:
             inputs = inputs[None]
         output = self.compiled_infer(inputs, **kwargs)[0]
         boxes = self.decode_output(output, inputs=inputs, **kwargs)
-        return {**infos, 'filename': filename, 'boxes': boxes, 'image': image, 'output': output.cpu().numpy()}
+        return {**infos, 'filename': filename, 'boxes': boxes, 'image': image,
+                'output': output if output_on_device else output.cpu().numpy()}
 
     def decode_output(self, output, inputs, normalize=True, nms_method='lanms', nms_threshold=None,
                       obj_threshold=None, **kwargs):

@@ -18,3 +18,7 @@ def get_model(model=None, lang=None):
 
 def ocr(image, *, model=None, lang='en', **kwargs):
     return get_model(model=model, lang=lang).predict(image, **kwargs)
+
+
+def stream(stream, *, model=None, lang='en', **kwargs):
+    return get_model(model=model, lang=lang).stream(stream, **kwargs)

@@ -4,8 +4,9 @@ models/ocr/crnn.py:15-58), running on libocrhip.so.
 Same defaults as the reference (`combine=True`, `method='beam_search'`, 10 beams).  Beam search runs on
 the host from the GPU logits; `method='greedy'` decodes on the GPU.  Callbacks and the `map.json` prediction cache
 (`predict(save=True)`) work as in the reference (utils/saving.py), so do `box_filters` (utils/filters.py);
-`dezoom_factor` scales every row's pixel box about its centre before the crop, as the reference does; the image saver,
-the displayer and camera streaming are not built.
+`dezoom_factor` scales every row's pixel box about its centre before the crop, as the reference does; `stream()`
+runs the reference's frame / text de-duplication over an iterable of frames; the image saver, the displayer and the
+camera / video readers are not built.
 """
 import logging
 import os
@@ -163,13 +164,14 @@ class BaseOCR:
         boxes = np.asarray(boxes, dtype=np.float32).reshape(-1, 4)
         if combine and len(boxes):
             from ...utils.combination import combine_boxes
-            boxes, _, rows = combine_boxes(boxes, **kwargs)
+            boxes, word_indices, rows = combine_boxes(boxes, **kwargs)
             rows = [np.asarray(r, dtype=np.float32).reshape(-1, 4) for r in rows]
         else:
             rows = [boxes[i:i + 1] for i in range(len(boxes))]
+            word_indices = [[[i]] for i in range(len(boxes))]
         if box_filters:                                     # base_ocr.py:164-165
             from ...utils.filters import filter_boxes
-            boxes, _, rows = filter_boxes(box_filters, boxes, list(range(len(boxes))), rows)
+            boxes, _, rows = filter_boxes(box_filters, boxes, list(word_indices), rows)
         flat_rows = np.concatenate(rows).reshape(-1, 4) if rows else np.zeros((0, 4), np.float32)
         owner = np.concatenate([np.full(len(r), i) for i, r in enumerate(rows)]) if rows else np.zeros((0,), int)
         index, texts, scores = self.recognise_rows(np.asarray(image), flat_rows, method=method, num_beams=num_beams,
@@ -196,6 +198,15 @@ class BaseOCR:
             infos = {k: v for k, v in output.items() if 'image' not in k}
             entry = apply_callbacks(callbacks, infos, output, save=True)
         return output if return_output else (predicted or {}).get(entry, {})
+
+    def stream(self, stream, *, detector='east', detector_kwargs=None, callback=None, post_processing=None, **kwargs):
+        """base_ocr.py:518-669 over an iterable of frames (arrays, file names): detection per frame, duplicate frames
+        and repeated / already emitted texts dropped, `callback(text)` for every new text.  Returns the
+        `streaming.OcrStream` that ran (`.emitted`: (frame index, result) pairs; `.state`).  See models/ocr/streaming.py;
+        cameras and video files are not opened here."""
+        from .streaming import run_stream
+        return run_stream(self, stream, detector=detector, detector_kwargs=detector_kwargs,
+                          callback=post_processing if post_processing is not None else callback, **kwargs)
 
     def get_inference_callbacks(self, *, save=True, directory=None, post_processing=None, **_):
         """base_ocr.py:310-368 without the image saver and the displayer: with `save`, the results already in
