@@ -55,6 +55,9 @@ def parse():
     ap.add_argument('--vocab', type=int, default=97, help='classes of the recogniser head (97 = english_g2, 6719 = zh_sim_g2)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32 = the reference's precision (the headline); bf16 = bfloat16 operands, float32 accumulation")
+    ap.add_argument('--rotated', action='store_true',
+                    help='opt-in path that keeps the quadrilaterals: rotated-IoU NMS + rotated crops (not the '
+                         'reference behaviour; the CPU baseline is skipped)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-pages', type=int, default=4)
     ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE',
@@ -116,14 +119,18 @@ def stage_accounting(pipe, d_img, d_maps):
     _, dec, kept = pipe.detect(d_img, d_maps)
     torch.cuda.synchronize()
     cand = dec['counts'].cpu().numpy().astype(np.int64)
-    n_iter = kept['n_iter'].cpu().numpy().astype(np.int64)
+    n_iter = kept['n_iter'].cpu().numpy().astype(np.int64) if 'n_iter' in kept else np.zeros(B, np.int64)
     counts = kept['counts'].cpu().numpy()
     boxes = kept['boxes'].cpu().numpy()
     src_px = out_elems = ctc_rows = 0
     for b in range(B):
-        p = S.plan_crops(boxes[b, :int(counts[b])], H, W)
-        r = p['rects'].astype(np.int64)
-        src_px += int(((r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1])).sum())
+        if pipe.rotated:
+            p = S.plan_crops_rotated(boxes[b, :int(counts[b])].reshape(-1, 4, 2), H, W)
+            src_px += int((p['geom'][:, 6].astype(np.int64) * p['geom'][:, 7].astype(np.int64)).sum())
+        else:
+            p = S.plan_crops(boxes[b, :int(counts[b])], H, W)
+            r = p['rects'].astype(np.int64)
+            src_px += int(((r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1])).sum())
         out_elems += int(64 * p['out_w'].astype(np.int64).sum())
         ctc_rows += int(pipe.ctx.seq_len(p['out_w']).sum())
     return {'decode_candidates': int(cand.sum()), 'decode_map_px': B * (H // 4) * (W // 4),
@@ -191,7 +198,8 @@ def main():
     east_params = random_east_params(seed=1)
     crnn_params = random_crnn_params(vocab_size=args.vocab, seed=2)
     from ocr_amd._lib import BF16, F32
-    pipe = OcrPipeline(east_params, crnn_params, device=local_rank, compute_dtype=BF16 if args.dtype == 'bf16' else F32)
+    pipe = OcrPipeline(east_params, crnn_params, device=local_rank, compute_dtype=BF16 if args.dtype == 'bf16' else F32,
+                       rotated=args.rotated)
 
     if args.share_gpu:
         pipe.ctx.set_option('lstm_persistent', 0)
@@ -275,6 +283,8 @@ def main():
                                       'rank 0 inside the timed region' % world,
                        'batches_taken_by_rank0': len(local)},
             **({'rehearsal': '--share-gpu: all ranks on one GPU, not a scaling result'} if args.share_gpu else {}),
+            **({'variant': '--rotated: rotated-IoU NMS + rotated crops, an opt-in extension, not the reference path'}
+               if args.rotated else {}),
             'words_per_s': words / elapsed,
             'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'launches': dom['launches'],
                          'avg_ms': dom['total_ms'] / dom['launches'], 'achieved': executed,
@@ -293,7 +303,7 @@ def main():
             'gpu_time': {'kernels_ms_per_step': gpu_ms / my_steps, 'all_mfma_conv_tflops_direct_equiv': conv_tflops,
                          'stages_ms_per_step': {s['name']: round(s['total_ms'] / my_steps, 3) for s in stats}},
         }
-        if world == 1 and not args.no_cpu_baseline and args.vocab == 97:
+        if world == 1 and not args.no_cpu_baseline and args.vocab == 97 and not args.rotated:
             line['cpu_baseline'] = cpu_baseline(images, maps, east_params, crnn_params, min(args.cpu_pages, B))
         print(json.dumps(line), flush=True)
     pipe.ctx.close()

@@ -213,6 +213,31 @@ int ocrhip_crop_resize_pack(ocrhip_handle h, const uint8_t* d_img, int B, int H,
                             const int64_t* d_dst_off, int n, int out_h, void* d_packed, int out_dtype,
                             ocrhip_stream stream);
 
+/* Opt-in extensions that keep the rotation of the detected quadrilaterals.  They have no counterpart in the
+ * reference, which collapses quadrilaterals to axis-aligned boxes before NMS
+ * (utils/image/bounding_box/non_max_suppression.py:27, converter.py:151-154) and crops axis-aligned slices
+ * (utils/image/bounding_box/processing.py:111-132; rotation raises NotImplementedError, converter.py:204).
+ *
+ * ocrhip_rotated_nms: greedy NMS on the quadrilaterals of ocrhip_east_decode (d_polys) with rotated IoU: repeatedly
+ * takes the remaining candidate with the highest score (lowest index among equals) and drops every remaining one
+ * whose IoU with it is >= iou_threshold (> 0).  IoU by clipping one convex quadrilateral with the other, float64.
+ *   d_polys (B,cap,8) float32 x,y of 4 corners; d_scores (B,cap); d_counts (B) candidates per image
+ *   d_out_polys (B,max_out,8), d_out_scores (B,max_out), d_out_index (B,max_out) int32 candidate index, in the order
+ *   taken (descending score); d_out_counts (B) int32 number kept (at most max_out)
+ *
+ * ocrhip_crop_rotated_pack: ocrhip_crop_resize_pack for oriented rectangles.  d_geom (n,8) float32 per crop:
+ * origin x, y (the text's top-left corner, pixels), step along the text (x, y), step across the text (x, y), crop
+ * width cw and height ch (whole numbers): cell (x, y) of the cw x ch crop is the bilinear interpolation of the
+ * page's gray values at origin + (x + 0.5) * step_along + (y + 0.5) * step_across (neighbours clamped to the page);
+ * the crop then takes the same resize / pad / normalise path as an axis-aligned one.  An unrotated rectangle on
+ * integer corners gives bit for bit the output of ocrhip_crop_resize_pack. */
+int ocrhip_rotated_nms(ocrhip_handle h, const float* d_polys, const float* d_scores, const int* d_counts, int B, int cap,
+                       float iou_threshold, int max_out, float* d_out_polys, float* d_out_scores, int* d_out_index,
+                       int* d_out_counts, ocrhip_stream stream);
+int ocrhip_crop_rotated_pack(ocrhip_handle h, const uint8_t* d_img, int B, int H, int W, const float* d_geom,
+                             const int* d_box_img, const int* d_inter, const int* d_out_w, const int64_t* d_dst_off,
+                             int n, int out_h, void* d_packed, int out_dtype, ocrhip_stream stream);
+
 /* ------------------------------------------------------------------------------------ CRNN --
  * Weights of CRNNCTC with the VGG extractor (architectures/crnn_arch.py:38-41,306-328,427-531),
  * keys of EasyOCR's recogniser checkpoints without the "module." prefix:

@@ -45,6 +45,10 @@ SIGNATURES = {
                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ocrhip_crop_resize_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    'ocrhip_crop_rotated_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    'ocrhip_rotated_nms': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
     'ocrhip_crnn_load_weights': (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_int]),
     'ocrhip_crnn_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ocrhip_crnn_vocab_size': (c_int, [c_void_p]),

@@ -492,8 +492,24 @@ int ocrhip_crop_resize_pack(ocrhip_handle h, const uint8_t* d_img, int B, int H,
                             const int* d_box_img, const int* d_inter, const int* d_out_w, const int64_t* d_dst_off,
                             int n, int out_h, void* d_packed, int out_dtype, ocrhip_stream stream) {
     OCR_HANDLE(h);
-    return launch_crop_resize_pack(d_img, B, H, W, d_rects, d_box_img, d_inter, d_out_w, d_dst_off, n, out_h, d_packed,
-                                   out_dtype, (hipStream_t)stream);
+    return launch_crop_resize_pack(d_img, B, H, W, d_rects, false, d_box_img, d_inter, d_out_w, d_dst_off, n, out_h,
+                                   d_packed, out_dtype, (hipStream_t)stream);
+}
+
+int ocrhip_crop_rotated_pack(ocrhip_handle h, const uint8_t* d_img, int B, int H, int W, const float* d_geom,
+                             const int* d_box_img, const int* d_inter, const int* d_out_w, const int64_t* d_dst_off,
+                             int n, int out_h, void* d_packed, int out_dtype, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    return launch_crop_resize_pack(d_img, B, H, W, d_geom, true, d_box_img, d_inter, d_out_w, d_dst_off, n, out_h,
+                                   d_packed, out_dtype, (hipStream_t)stream);
+}
+
+int ocrhip_rotated_nms(ocrhip_handle h, const float* d_polys, const float* d_scores, const int* d_counts, int B, int cap,
+                       float iou_threshold, int max_out, float* d_out_polys, float* d_out_scores, int* d_out_index,
+                       int* d_out_counts, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    return launch_rotated_nms(h, d_polys, d_scores, d_counts, B, cap, iou_threshold, max_out, d_out_polys, d_out_scores,
+                              d_out_index, d_out_counts, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------ CRNN

@@ -39,6 +39,7 @@ SOURCES = {
     'rnn_persistent.hip': [],
     'pool.hip': [],
     'metrics.hip': ['-ffp-contract=off'],
+    'rnms.hip': ['-ffp-contract=off'],
 }
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 'ocrhip.h')]
 

@@ -236,7 +236,10 @@ int launch_lanms(ocrhip_ctx* h, const float* xyxy, const float* scores, const in
                  hipStream_t s);
 
 // crop.hip
-int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* rects, const int* box_img,
+int launch_rotated_nms(ocrhip_ctx* h, const float* polys, const float* scores, const int* counts, int B, int cap,
+                       float iou_threshold, int max_out, float* out_polys, float* out_scores, int* out_index,
+                       int* out_counts, hipStream_t s);
+int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const void* rects, bool rotated, const int* box_img,
                             const int* inter, const int* out_w, const int64_t* dst_off, int n, int out_h,
                             void* packed, int out_dtype, hipStream_t s);
 

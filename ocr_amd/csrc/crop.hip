@@ -61,10 +61,38 @@ __device__ __forceinline__ float gray_at(const uint8_t* __restrict__ img, int W,
     return v;
 }
 
+// Where a crop takes its pixels from.  ROT = false: the slice of the page that starts at (x0, y0).  ROT = true (an
+// extension, the reference crops axis-aligned slices only: utils/image/bounding_box/processing.py:111-132): an
+// oriented rectangle; cell (x, y) of the crop has its centre at origin + (x + 0.5) * step_x + (y + 0.5) * step_y in
+// page coordinates and takes the bilinear interpolation of the page's gray values there (neighbours clamped to the
+// page).  An unrotated rectangle on integer corners samples pixel centres: exactly the slice.
+template <bool ROT>
+struct Source {
+    const uint8_t* img;
+    int W, H, x0, y0;
+    float ox, oy, sxx, sxy, syx, syy;
+    __device__ __forceinline__ float at(int y, int x) const {
+        if (!ROT) return gray_at(img, W, y0 + y, x0 + x);
+        const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+        const float px = (ox + fx * sxx) + fy * syx;
+        const float py = (oy + fx * sxy) + fy * syy;
+        const float qx = px - 0.5f, qy = py - 0.5f;
+        const float flx = floorf(qx), fly = floorf(qy);
+        const float tx = qx - flx, ty = qy - fly;
+        // clamped in float first: a far-away coordinate must not overflow the integer conversion
+        const int ix = (int)fminf(fmaxf(flx, -1.0f), (float)W), iy = (int)fminf(fmaxf(fly, -1.0f), (float)H);
+        const int xa = min(max(ix, 0), W - 1), xb = min(max(ix + 1, 0), W - 1);
+        const int ya = min(max(iy, 0), H - 1), yb = min(max(iy + 1, 0), H - 1);
+        const float top = gray_at(img, W, ya, xa) * (1.0f - tx) + gray_at(img, W, ya, xb) * tx;
+        const float bot = gray_at(img, W, yb, xa) * (1.0f - tx) + gray_at(img, W, yb, xb) * tx;
+        return top * (1.0f - ty) + bot * ty;
+    }
+};
+
 // horizontally resized gray value of source row y (crop coordinates) at resized column sx
-__device__ __forceinline__ float hsample(const uint8_t* __restrict__ img, int W, int x0, int yy, const Axis& ax,
-                                         int sx) {
-    if (ax.identity) return gray_at(img, W, yy, x0 + sx);
+template <bool ROT>
+__device__ __forceinline__ float hsample(const Source<ROT>& src, int yy, const Axis& ax, int sx) {
+    if (ax.identity) return src.at(yy, sx);
     float center;
     int lo, cnt;
     tap_range(ax, sx, center, lo, cnt);
@@ -74,15 +102,17 @@ __device__ __forceinline__ float hsample(const uint8_t* __restrict__ img, int W,
     for (int j = 0; j < cnt; ++j) {
         float w = tap_weight(ax, center, lo, j);
         if (total != 0.0f) w = w / total;
-        const float term = gray_at(img, W, yy, x0 + lo + j) * w;
+        const float term = src.at(yy, lo + j) * w;
         acc = (j == 0) ? term : (acc + term);
     }
     return acc;
 }
 
-template <bool BF16>
+// rects: ROT = false: (n,4) int32 x0, y0, x1, y1 in pixels; ROT = true: (n,8) float32 origin x, y, step_x (x, y),
+// step_y (x, y), crop width, crop height (whole numbers)
+template <bool BF16, bool ROT>
 __global__ __launch_bounds__(256) void crop_resize_pack_kernel(const uint8_t* __restrict__ img, int B, int H, int W,
-                                                               const int* __restrict__ rects,
+                                                               const void* __restrict__ rects_v,
                                                                const int* __restrict__ box_img,
                                                                const int* __restrict__ inter,
                                                                const int* __restrict__ out_w_arr,
@@ -91,13 +121,31 @@ __global__ __launch_bounds__(256) void crop_resize_pack_kernel(const uint8_t* __
     const int n = blockIdx.x;
     int b = box_img[n];
     b = min(max(b, 0), B - 1);
-    // the rectangle is clamped to the image so that a bad rectangle can never read out of bounds
-    int x0 = min(max(rects[4 * n + 0], 0), W - 1), y0 = min(max(rects[4 * n + 1], 0), H - 1);
-    int x1 = min(max(rects[4 * n + 2], x0 + 1), W), y1 = min(max(rects[4 * n + 3], y0 + 1), H);
-    const int ch = y1 - y0, cw = x1 - x0;
+    Source<ROT> src;
+    src.img = img + (int64_t)b * H * W * 3;
+    src.W = W;
+    src.H = H;
+    int ch, cw;
+    if (ROT) {
+        const float* g = reinterpret_cast<const float*>(rects_v) + 8 * (int64_t)n;
+        src.ox = g[0]; src.oy = g[1]; src.sxx = g[2]; src.sxy = g[3]; src.syx = g[4]; src.syy = g[5];
+        src.x0 = src.y0 = 0;
+        // every read is clamped to the page, so any geometry is safe; the size only has to be sane
+        cw = (int)fminf(fmaxf(g[6], 1.0f), 65536.0f);
+        ch = (int)fminf(fmaxf(g[7], 1.0f), 65536.0f);
+    } else {
+        const int* rects = reinterpret_cast<const int*>(rects_v);
+        // the rectangle is clamped to the image so that a bad rectangle can never read out of bounds
+        const int x0 = min(max(rects[4 * n + 0], 0), W - 1), y0 = min(max(rects[4 * n + 1], 0), H - 1);
+        const int x1 = min(max(rects[4 * n + 2], x0 + 1), W), y1 = min(max(rects[4 * n + 3], y0 + 1), H);
+        src.x0 = x0;
+        src.y0 = y0;
+        src.ox = src.oy = src.sxx = src.sxy = src.syx = src.syy = 0.0f;
+        ch = y1 - y0;
+        cw = x1 - x0;
+    }
     const int out_w = out_w_arr[n];
     const int ih = min(max(inter[2 * n + 0], 1), out_h), iw = min(max(inter[2 * n + 1], 1), out_w);
-    const uint8_t* src = img + (int64_t)b * H * W * 3;
     const Axis ax = make_axis(cw, iw), ay = make_axis(ch, ih);
     const int64_t dst = dst_off[n];
 
@@ -110,7 +158,7 @@ __global__ __launch_bounds__(256) void crop_resize_pack_kernel(const uint8_t* __
         const int sy = min(oy, ih - 1), sx = min(ox, iw - 1);     // repeat_last: right, then bottom
         float v;
         if (ay.identity) {
-            v = hsample(src, W, x0, y0 + sy, ax, sx);
+            v = hsample(src, sy, ax, sx);
         } else {
             float center;
             int lo, cnt;
@@ -121,7 +169,7 @@ __global__ __launch_bounds__(256) void crop_resize_pack_kernel(const uint8_t* __
             for (int j = 0; j < cnt; ++j) {
                 float w = tap_weight(ay, center, lo, j);
                 if (total_w != 0.0f) w = w / total_w;
-                const float term = hsample(src, W, x0, y0 + lo + j, ax, sx) * w;
+                const float term = hsample(src, lo + j, ax, sx) * w;
                 v = (j == 0) ? term : (v + term);
             }
         }
@@ -214,7 +262,7 @@ int launch_resize_rgb_norm(const void* img, bool is_u8, int B, int H, int W, int
     return OCRHIP_OK;
 }
 
-int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* rects, const int* box_img,
+int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const void* rects, bool rotated, const int* box_img,
                             const int* inter, const int* out_w, const int64_t* dst_off, int n, int out_h,
                             void* packed, int out_dtype, hipStream_t s) {
     OCR_REQUIRE(img && rects && box_img && inter && out_w && dst_off && packed, "crop_resize_pack: null argument");
@@ -223,13 +271,16 @@ int launch_crop_resize_pack(const uint8_t* img, int B, int H, int W, const int* 
     OCR_REQUIRE(out_dtype == OCRHIP_F32 || out_dtype == OCRHIP_BF16, "crop_resize_pack: out_dtype must be F32 or BF16");
     if (n == 0) return OCRHIP_OK;
     dim3 grid(n, 4), block(256);
-    ProfScope prof("crop_resize_pack", 0.0, 0.0, s);
-    if (out_dtype == OCRHIP_BF16)
-        hipLaunchKernelGGL(crop_resize_pack_kernel<true>, grid, block, 0, s, img, B, H, W, rects, box_img, inter, out_w,
-                           dst_off, out_h, packed);
-    else
-        hipLaunchKernelGGL(crop_resize_pack_kernel<false>, grid, block, 0, s, img, B, H, W, rects, box_img, inter, out_w,
-                           dst_off, out_h, packed);
+    ProfScope prof(rotated ? "crop_rotated_pack" : "crop_resize_pack", 0.0, 0.0, s);
+#define OCR_CROP_LAUNCH(BF, ROT)                                                                                        \
+    hipLaunchKernelGGL((crop_resize_pack_kernel<BF, ROT>), grid, block, 0, s, img, B, H, W, rects, box_img, inter, out_w, \
+                       dst_off, out_h, packed)
+    if (out_dtype == OCRHIP_BF16) {
+        if (rotated) OCR_CROP_LAUNCH(true, true); else OCR_CROP_LAUNCH(true, false);
+    } else {
+        if (rotated) OCR_CROP_LAUNCH(false, true); else OCR_CROP_LAUNCH(false, false);
+    }
+#undef OCR_CROP_LAUNCH
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }

@@ -230,6 +230,38 @@ class HipContext:
                                                _ptr(out_w), _ptr(dst_off), n, int(out_h), _ptr(packed), code, _stream()))
         return packed
 
+    def crop_rotated_pack(self, images, geom, box_img, inter_hw, out_w, dst_off, total_elems, out_h=64,
+                          out_dtype=torch.float32):
+        """`crop_resize_pack` for oriented rectangles: geom (n,8) float32 = origin x, y, step along the text (x, y),
+        step across the text (x, y), crop width, crop height (see `utils.image_sizes.plan_crops_rotated`)."""
+        assert images.is_cuda and images.dtype == torch.uint8 and images.is_contiguous()
+        assert geom.dtype == torch.float32 and geom.is_contiguous() and geom.shape[1] == 8
+        B, H, W, _ = images.shape
+        n = int(geom.shape[0])
+        packed = torch.empty((int(total_elems),), dtype=out_dtype, device=images.device)
+        code = F32 if out_dtype == torch.float32 else BF16
+        check(self.lib.ocrhip_crop_rotated_pack(self._h, _ptr(images), B, H, W, _ptr(geom), _ptr(box_img), _ptr(inter_hw),
+                                                _ptr(out_w), _ptr(dst_off), n, int(out_h), _ptr(packed), code, _stream()))
+        return packed
+
+    def rotated_nms(self, polys, scores, counts, iou_threshold, max_out=2048):
+        """Greedy NMS with rotated IoU on decoded quadrilaterals: polys (B,cap,4,2) or (B,cap,8) float32, scores
+        (B,cap), counts (B,) int32, all on the GPU -> dict(polys (B,max_out,4,2), scores, index (B,max_out) int32,
+        counts (B,) int32), kept quadrilaterals in descending score order."""
+        assert polys.is_cuda and polys.dtype == torch.float32 and polys.is_contiguous()
+        assert scores.dtype == torch.float32 and scores.is_contiguous() and counts.dtype == torch.int32
+        B, cap = int(scores.shape[0]), int(scores.shape[1])
+        assert polys.numel() == B * cap * 8
+        dev = polys.device
+        out = {'polys': torch.zeros((B, int(max_out), 4, 2), dtype=torch.float32, device=dev),
+               'scores': torch.zeros((B, int(max_out)), dtype=torch.float32, device=dev),
+               'index': torch.full((B, int(max_out)), -1, dtype=torch.int32, device=dev),
+               'counts': torch.zeros((B,), dtype=torch.int32, device=dev)}
+        check(self.lib.ocrhip_rotated_nms(self._h, _ptr(polys), _ptr(scores), _ptr(counts), B, cap, float(iou_threshold),
+                                          int(max_out), _ptr(out['polys']), _ptr(out['scores']), _ptr(out['index']),
+                                          _ptr(out['counts']), _stream()))
+        return out
+
     # ------------------------------------------------------------------ CRNN
     def crnn_load_weights(self, state_dict):
         arr, keep = _descs(state_dict)

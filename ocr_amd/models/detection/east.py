@@ -118,6 +118,14 @@ class EAST:
         if not use_nms:
             return {'boxes': dec['polys'][0, :n].cpu().numpy(), 'scores': dec['scores'][0, :n].cpu().numpy(),
                     'format': 'poly'}
+        if nms_method in ('rotated', 'rotated_nms'):
+            # opt-in, not in the reference: the quadrilaterals keep their rotation through a greedy NMS with rotated IoU
+            dec = self.ctx.east_decode(maps, in_hw, obj_threshold, with_polys=True)
+            out = self.ctx.rotated_nms(dec['polys'], dec['scores'], dec['counts'], nms_threshold,
+                                       max_out=kwargs.get('max_output_size') or 2048)
+            m = int(out['counts'][0].item())
+            return {'boxes': out['polys'][0, :m].cpu().numpy(), 'scores': out['scores'][0, :m].cpu().numpy(),
+                    'format': 'poly'}
         if nms_method in ('lanms', 'locality_aware_nms'):
             out = self.ctx.lanms(dec['xyxy'], dec['scores'], dec['counts'],
                                  merge_threshold=kwargs.get('merge_threshold', self.merge_threshold),

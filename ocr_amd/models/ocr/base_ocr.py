@@ -17,7 +17,7 @@ import torch
 from .. import register_model
 from ..detection.east import get_image_data, load_image
 from ...runtimes import HIPRuntime
-from ...utils.image_sizes import plan_crops, quantise_u8
+from ...utils.image_sizes import plan_crops, plan_crops_rotated, quantise_u8
 from ...utils.saving import FunctionCallback, JSONSaver, QueueCallback, apply_callbacks, load_json
 from ...utils.text import CharTokenizer, ENGLISH_G2_CHARACTERS
 
@@ -81,19 +81,27 @@ class BaseOCR:
     def _pack(self, d_images, boxes_per_image, dezoom_factor=1.):
         B, H, W, _ = d_images.shape
         plans, box_img = [], []
+        rotated = any(np.ndim(boxes) == 3 for boxes in boxes_per_image)      # (m,4,2) quadrilaterals
         for b, boxes in enumerate(boxes_per_image):
-            p = plan_crops(boxes, H, W, dezoom_factor=dezoom_factor)
+            if rotated:
+                if dezoom_factor != 1.:
+                    raise NotImplementedError('dezoom_factor is not supported for quadrilaterals')    # converter.py:204
+                p = plan_crops_rotated(boxes, H, W)
+            else:
+                p = plan_crops(boxes, H, W, dezoom_factor=dezoom_factor)
             plans.append(p)
             box_img.append(np.full(len(p['index']), b, dtype=np.int32))
-        plan = {k: np.concatenate([p[k] for p in plans]) for k in ('rects', 'inter', 'out_w', 'index')}
+        rect_key = 'geom' if rotated else 'rects'
+        plan = {k: np.concatenate([p[k] for p in plans]) for k in (rect_key, 'inter', 'out_w', 'index')}
         plan['box_img'] = np.concatenate(box_img)
         n = len(plan['out_w'])
         if n == 0:
             return None
         off = np.concatenate([[0], np.cumsum(64 * plan['out_w'].astype(np.int64))])
         dev = d_images.device
-        packed = self.ctx.crop_resize_pack(
-            d_images, torch.from_numpy(plan['rects']).to(dev), torch.from_numpy(plan['box_img']).to(dev),
+        crop = self.ctx.crop_rotated_pack if rotated else self.ctx.crop_resize_pack
+        packed = crop(
+            d_images, torch.from_numpy(plan[rect_key]).to(dev), torch.from_numpy(plan['box_img']).to(dev),
             torch.from_numpy(plan['inter']).to(dev), torch.from_numpy(plan['out_w']).to(dev),
             torch.from_numpy(off[:-1].astype(np.int64)).to(dev), int(off[-1]))
         return packed, plan, off
@@ -111,7 +119,9 @@ class BaseOCR:
         if image.shape[2] == 1:
             image = np.repeat(image, 3, axis=2)
         d_img = torch.from_numpy(np.ascontiguousarray(image)).to(self.ctx.device)[None]
-        out = self._pack(d_img, [np.asarray(rows, dtype=np.float32).reshape(-1, 4)], dezoom_factor=dezoom_factor)
+        rows = np.asarray(rows, dtype=np.float32)
+        rows = rows.reshape(-1, 4, 2) if rows.ndim == 3 else rows.reshape(-1, 4)      # quadrilaterals or xyxy
+        out = self._pack(d_img, [rows], dezoom_factor=dezoom_factor)
         if out is None:
             return [], [], np.zeros((0,), np.float32)
         packed, plan, off = out
@@ -161,7 +171,13 @@ class BaseOCR:
         boxes = data['boxes']
         if isinstance(boxes, dict):
             boxes = boxes['boxes']
-        boxes = np.asarray(boxes, dtype=np.float32).reshape(-1, 4)
+        boxes = np.asarray(boxes, dtype=np.float32)
+        quads = boxes.reshape(-1, 4, 2) if boxes.ndim == 3 else None      # 'poly' boxes of nms_method='rotated' (opt-in)
+        if quads is not None:
+            # grouping and filters work on axis-aligned bounds; every quadrilateral stays one recogniser input
+            boxes = np.concatenate([quads.min(axis=1), quads.max(axis=1)], axis=1)
+            combine = False
+        boxes = boxes.reshape(-1, 4)
         if combine and len(boxes):
             from ...utils.combination import combine_boxes
             boxes, word_indices, rows = combine_boxes(boxes, **kwargs)
@@ -171,8 +187,10 @@ class BaseOCR:
             word_indices = [[[i]] for i in range(len(boxes))]
         if box_filters:                                     # base_ocr.py:164-165
             from ...utils.filters import filter_boxes
-            boxes, _, rows = filter_boxes(box_filters, boxes, list(word_indices), rows)
+            boxes, word_indices, rows = filter_boxes(box_filters, boxes, list(word_indices), rows)
         flat_rows = np.concatenate(rows).reshape(-1, 4) if rows else np.zeros((0, 4), np.float32)
+        if quads is not None:
+            flat_rows = quads[[idx[0][0] for idx in word_indices]] if len(word_indices) else np.zeros((0, 4, 2), np.float32)
         owner = np.concatenate([np.full(len(r), i) for i, r in enumerate(rows)]) if rows else np.zeros((0,), int)
         index, texts, scores = self.recognise_rows(np.asarray(image), flat_rows, method=method, num_beams=num_beams,
                                                    dezoom_factor=dezoom_factor)
@@ -188,6 +206,8 @@ class BaseOCR:
                 continue
             info = {'boxes': boxes[i], 'rows': rows_i, 'text': ' \n'.join(texts[k] for k in sel), 'format': 'xyxy',
                     'scores': sc}
+            if quads is not None:
+                info['quad'] = flat_rows[i]
             ocr_results.append(info)
             if box_callback is not None:
                 box_callback(info, image=image)

@@ -10,6 +10,11 @@ once per image / once per text row:
 
 Only two small device->host copies per batch: the kept boxes (to compute crop sizes with the
 reference's float32/float64 host arithmetic) and the token ids.
+
+`rotated=True` (opt-in, not the reference's behaviour: it collapses quadrilaterals to axis-aligned boxes and crops
+axis-aligned slices) keeps the detector's quadrilaterals instead: greedy NMS with rotated IoU on the decoded
+candidates, then every kept quadrilateral is rectified by bilinear sampling into the recogniser input; `boxes` of the
+results are (m,4,2) corner arrays.
 """
 import numpy as np
 import torch
@@ -21,7 +26,8 @@ from .utils.text import CharTokenizer
 
 class OcrPipeline:
     def __init__(self, east_params, crnn_params, device=0, tokenizer=None, obj_threshold=0.35, nms_threshold=0.2,
-                 merge_threshold=0.3, merge_method='union', max_crop_elems=1 << 20, ctx=None, compute_dtype=F32):
+                 merge_threshold=0.3, merge_method='union', max_crop_elems=1 << 20, ctx=None, compute_dtype=F32,
+                 rotated=False):
         self.ctx = ctx or HipContext(device)
         self.compute_dtype = compute_dtype          # F32 (the reference's precision) or BF16 operands with float32 accumulation
         self.device = self.ctx.device
@@ -35,6 +41,7 @@ class OcrPipeline:
         self.merge_threshold = merge_threshold
         self.merge_method = merge_method
         self.max_crop_elems = max_crop_elems
+        self.rotated = rotated
 
     # ---- detection --------------------------------------------------------------------------
     def detect(self, images, maps_override=None):
@@ -45,6 +52,11 @@ class OcrPipeline:
         B, H, W, _ = images.shape
         maps = self.ctx.east_forward(images, compute_dtype=self.compute_dtype)
         used = maps if maps_override is None else maps_override
+        if self.rotated:
+            dec = self.ctx.east_decode(used, (H, W), self.obj_threshold, with_polys=True)
+            kept = self.ctx.rotated_nms(dec['polys'], dec['scores'], dec['counts'], self.nms_threshold, max_out=self.KEEP_CAP)
+            return maps, dec, {'boxes': kept['polys'].view(B, self.KEEP_CAP, 8), 'scores': kept['scores'],
+                               'counts': kept['counts']}
         dec = self.ctx.east_decode(used, (H, W), self.obj_threshold)
         kept = self.ctx.lanms(dec['xyxy'], dec['scores'], dec['counts'], merge_threshold=self.merge_threshold,
                               nms_threshold=self.nms_threshold, merge_method=self.merge_method)
@@ -58,7 +70,7 @@ class OcrPipeline:
         B = images.shape[0]
         _, _, kept = self.detect(images, maps_override)
         k = min(self.KEEP_CAP, kept['boxes'].shape[1])
-        h_boxes = torch.empty((B, k, 4), dtype=torch.float32, pin_memory=True)
+        h_boxes = torch.empty((B, k, kept['boxes'].shape[2]), dtype=torch.float32, pin_memory=True)
         h_counts = torch.empty((B,), dtype=torch.int32, pin_memory=True)
         h_boxes.copy_(kept['boxes'][:, :k], non_blocking=True)
         h_counts.copy_(kept['counts'], non_blocking=True)
@@ -76,11 +88,19 @@ class OcrPipeline:
             boxes = st['kept']['boxes'][:, :int(counts.max())].cpu().numpy()
         else:
             boxes = st['h_boxes'].numpy()
+        rotated = boxes.shape[2] == 8
         per_image = [boxes[b, :int(counts[b])].copy() for b in range(B)]
+        if rotated:
+            per_image = [bx.reshape(-1, 4, 2) for bx in per_image]
         st['per_image'] = per_image
         st['kept'] = None
-        plans = [S.plan_crops(bx, H, W) for bx in per_image]
-        rects = np.concatenate([p['rects'] for p in plans])
+        if rotated:
+            plans = [S.plan_crops_rotated(bx, H, W) for bx in per_image]
+            # the kernel reads 8 floats per crop where the axis-aligned one reads 4 integers: same buffer, bits kept
+            rects = np.concatenate([p['geom'] for p in plans]).view(np.int32)
+        else:
+            plans = [S.plan_crops(bx, H, W) for bx in per_image]
+            rects = np.concatenate([p['rects'] for p in plans])
         inter = np.concatenate([p['inter'] for p in plans])
         out_w = np.concatenate([p['out_w'] for p in plans])
         box_idx = np.concatenate([p['index'] for p in plans])
@@ -99,9 +119,14 @@ class OcrPipeline:
         h_off = torch.from_numpy(off[:-1].astype(np.int64)).pin_memory()
         meta = h_meta.to(dev, non_blocking=True)
         d_off = h_off.to(dev, non_blocking=True)
-        d_rects, d_inter = meta[:4 * n].view(n, 4), meta[4 * n:6 * n].view(n, 2)
-        d_out_w, d_box_img = meta[6 * n:7 * n], meta[7 * n:8 * n]
-        packed = self.ctx.crop_resize_pack(images, d_rects, d_box_img, d_inter, d_out_w, d_off, int(off[-1]))
+        r = rects.shape[1]                                   # 4 integers or 8 floats per crop
+        d_rects, d_inter = meta[:r * n].view(n, r), meta[r * n:(r + 2) * n].view(n, 2)
+        d_out_w, d_box_img = meta[(r + 2) * n:(r + 3) * n], meta[(r + 3) * n:(r + 4) * n]
+        if rotated:
+            packed = self.ctx.crop_rotated_pack(images, d_rects.view(torch.float32), d_box_img, d_inter, d_out_w, d_off,
+                                                int(off[-1]))
+        else:
+            packed = self.ctx.crop_resize_pack(images, d_rects, d_box_img, d_inter, d_out_w, d_off, int(off[-1]))
         out = self.ctx.crnn_forward_packed(packed, out_w, compute_dtype=self.compute_dtype)
         h_tokens = torch.empty(out['tokens'].shape, dtype=torch.int32, pin_memory=True)
         h_scores = torch.empty(out['scores'].shape, dtype=torch.float32, pin_memory=True)

@@ -121,12 +121,12 @@ def teacher_maps(rng, boxes, H, W, scale=4, shrink=0.3):
     return out.astype(np.float32)
 
 
-def make_pages(seed, n_pages, H, W, n_words=200):
+def make_pages(seed, n_pages, H, W, n_words=200, **layout_kw):
     """-> images (n,H,W,3) uint8, maps (n,H/4,W/4,6) float32, list of word lists."""
     rng = np.random.default_rng(seed)
     imgs, maps, words = [], [], []
     for _ in range(n_pages):
-        img, boxes = render_page(rng, H, W, n_words)
+        img, boxes = render_page(rng, H, W, n_words, **layout_kw)
         imgs.append(img)
         maps.append(teacher_maps(rng, boxes, H, W))
         words.append(boxes)

@@ -76,6 +76,47 @@ def dezoom_absolute(abs_boxes, factor, image_h, image_w):
     return np.stack([nx, ny, nx + nw, ny + nh], axis=1)
 
 
+def _network_sizes(ch, cw, height, multiple):
+    """Crop sizes (int arrays) -> (padded width, intermediate height, intermediate width, valid) as the reference
+    sizes a recogniser input (get_output_size + resize_image, utils/image/image_processing.py:54-79,202-242)."""
+    valid = (cw > 0) & (ch > 0)
+    chs, cws = np.maximum(ch, 1), np.maximum(cw, 1)
+    # get_output_size: ratio = max(height / h, -1 / w) in float64, W' = int32(w * ratio), next multiple
+    ratio = np.maximum(np.float64(height) / chs.astype(np.float64), -1.0 / cws.astype(np.float64))
+    w_out = (cws.astype(np.float64) * ratio).astype(np.int32).astype(np.int64)
+    w_out = np.where(w_out % multiple != 0, (w_out // multiple + 1) * multiple, w_out)
+    # resize_image: intermediate = int32(float32(hw) * min(float32(out) / float32(hw)))
+    hf, wf = chs.astype(np.float32), cws.astype(np.float32)
+    r32 = np.minimum(np.float32(height) / hf, w_out.astype(np.float32) / wf)
+    ih, iw = (hf * r32).astype(np.int32), (wf * r32).astype(np.int32)
+    valid = valid & (w_out > 0) & (ih > 0) & (iw > 0)
+    return w_out, ih, iw, valid
+
+
+def plan_crops_rotated(quads_rel, image_h, image_w, height=64, multiple=64):
+    """`plan_crops` for quadrilaterals (opt-in, not in the reference): quads_rel (m,4,2) relative corners in the
+    order top-left, top-right, bottom-right, bottom-left of the text, as the detector's decode writes them.
+    The crop is the parallelogram spanned from the top-left corner by the top and the left edge, cw x ch cells with
+    cw, ch = the edge lengths in pixels rounded to whole numbers.  Returns dict(geom (m,8) float32 = origin x, y,
+    step along the text (x, y), step across (x, y), cw, ch; inter, out_w, index as `plan_crops`)."""
+    q = np.asarray(quads_rel, dtype=np.float32).reshape(-1, 4, 2) * np.array([image_w, image_h], dtype=np.float32)
+    finite = np.isfinite(q).all(axis=(1, 2))
+    q = np.where(finite[:, None, None], q, np.float32(0))
+    top, left = q[:, 1] - q[:, 0], q[:, 3] - q[:, 0]
+    len_top = np.minimum(np.sqrt(top[:, 0] * top[:, 0] + top[:, 1] * top[:, 1]), np.float32(1e9))
+    len_left = np.minimum(np.sqrt(left[:, 0] * left[:, 0] + left[:, 1] * left[:, 1]), np.float32(1e9))
+    cw = np.maximum(1, np.rint(len_top)).astype(np.int64)
+    ch = np.maximum(1, np.rint(len_left)).astype(np.int64)
+    finite &= (cw < 65536) & (ch < 65536)
+    cw, ch = np.where(finite, cw, 0), np.where(finite, ch, 0)
+    w_out, ih, iw, valid = _network_sizes(ch, cw, height, multiple)
+    keep = np.nonzero(valid)[0]
+    cwf, chf = np.maximum(cw, 1).astype(np.float32)[:, None], np.maximum(ch, 1).astype(np.float32)[:, None]
+    geom = np.concatenate([q[:, 0], top / cwf, left / chf, cwf, chf], axis=1).astype(np.float32)
+    return {'geom': geom[keep].reshape(-1, 8), 'inter': np.stack([ih, iw], axis=1)[keep].astype(np.int32).reshape(-1, 2),
+            'out_w': w_out[keep].astype(np.int32), 'index': keep.astype(np.int64)}
+
+
 def plan_crops(boxes_rel, image_h, image_w, height=64, multiple=64, dezoom_factor=1.):
     """Everything the crop kernel needs for the boxes of one image (vectorised over the boxes).
 
@@ -89,17 +130,7 @@ def plan_crops(boxes_rel, image_h, image_w, height=64, multiple=64, dezoom_facto
     x0, x1 = _resolve_index(ab[:, 0], image_w), _resolve_index(ab[:, 2], image_w)
     y0, y1 = _resolve_index(ab[:, 1], image_h), _resolve_index(ab[:, 3], image_h)
     cw, ch = x1 - x0, y1 - y0
-    valid = (cw > 0) & (ch > 0)
-    chs, cws = np.maximum(ch, 1), np.maximum(cw, 1)
-    # get_output_size: ratio = max(height / h, -1 / w) in float64, W' = int32(w * ratio), next multiple
-    ratio = np.maximum(np.float64(height) / chs.astype(np.float64), -1.0 / cws.astype(np.float64))
-    w_out = (cws.astype(np.float64) * ratio).astype(np.int32).astype(np.int64)
-    w_out = np.where(w_out % multiple != 0, (w_out // multiple + 1) * multiple, w_out)
-    # resize_image: intermediate = int32(float32(hw) * min(float32(out) / float32(hw)))
-    hf, wf = chs.astype(np.float32), cws.astype(np.float32)
-    r32 = np.minimum(np.float32(height) / hf, w_out.astype(np.float32) / wf)
-    ih, iw = (hf * r32).astype(np.int32), (wf * r32).astype(np.int32)
-    valid &= (w_out > 0) & (ih > 0) & (iw > 0)
+    w_out, ih, iw, valid = _network_sizes(ch, cw, height, multiple)
     keep = np.nonzero(valid)[0]
     rects = np.stack([x0, y0, x1, y1], axis=1)[keep].astype(np.int32)
     return {'rects': rects.reshape(-1, 4), 'inter': np.stack([ih, iw], axis=1)[keep].astype(np.int32).reshape(-1, 2),
