@@ -53,9 +53,13 @@ constexpr int kOS = 64 + 4;                     // floats per staged output pixe
 constexpr int kPartFloats = 128 * kOS;          // one wave group's share of a block row (4 x 32 pixels x 64 channels)
 constexpr int kStageFloats = 4 * kPartFloats;
 constexpr int kLdsBytes = 4 * (kLoopFloats > kStageFloats ? kLoopFloats : kStageFloats);
+// MODE 4 (half tiles): two U of 16 blocks and two raw tiles of 10 rows; or the staged 8 x 32 output tile
+constexpr int kLoopFloats4 = 2 * (36 * 16 * kCK) + 2 * (kRawW * 10 * kRS + 4);
+constexpr int kStageFloats4 = 8 * 32 * kOS;
+constexpr int kLdsBytes4 = 4 * (kLoopFloats4 > kStageFloats4 ? kLoopFloats4 : kStageFloats4);
 constexpr int kWChunkFloats = 36 * 2 * 64 * 4;  // transformed filters of one chunk of one 64-channel block
 constexpr int kSplitMinCin = 512;               // layers at least this deep run as transform kernel + multiply kernel
-constexpr int kWaveTileMaxCin = 256;            // fused layers shallower than this run MODE 3 (few chunks: the cheap epilogue pays), the others MODE 0 (half the operand loads per MFMA)
+constexpr int kWaveTileMaxCin = 256;            // wino4_wave_tiles = 1: fused layers shallower than this run MODE 3 (few chunks: the cheap epilogue pays), the others MODE 0 (half the operand loads per MFMA)
 
 struct Wino4Args {
     const float* x;        // (B,H,W,cin)
@@ -119,9 +123,19 @@ __device__ __forceinline__ void inverse_part(const float (&M)[3][3], float (&Y)[
 //          row at a time between eight barriers, in MODE 0.  The price: a block's transformed data is read from LDS by
 //          four waves instead of two, and a filter fragment is loaded by two waves instead of one (both have room).
 //          Same arithmetic as MODE 0 up to the order of the additions in the inverse transform.
+//   MODE 4 is MODE 3 on half a tile: a workgroup of 4 waves computes 8 x 32 outputs (2 x 8 blocks) x 64 channels, wave
+//          cq owns all 36 components of its 16 blocks x 16 channels.  Same instructions per wave and per output as
+//          MODE 3, but half the LDS, so TWO workgroups share a CU: while one waits (first loads of a tile, its barriers,
+//          the stores of its epilogue) the other one's waves issue.  Maps of 8 rows are one tile per image.
 template <int POOL, int MODE>
-__global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args a) {
+__global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv_wino4_f32_kernel(const Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // U[2] then raw[2]: chunk j lives in buffer j & 1
+    constexpr bool W3 = (MODE == 3 || MODE == 4);          // the variants whose waves own whole (block, channel) tiles
+    constexpr int NT = (MODE == 4) ? 256 : 512;            // threads
+    constexpr int NBLK = (MODE == 4) ? 16 : 32;            // 4x4 blocks of a workgroup's tile
+    constexpr int TH = NBLK / 2;                           // output rows of the tile
+    constexpr int UC = NBLK * kCK, UF = 36 * UC;           // floats per component of U, per U
+    constexpr int RH = (MODE == 4) ? 10 : kRawH, RPX = kRawW * RH, RF = RPX * kRS, RB = RF + 4;      // raw tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     const int tile_all = (int)(work / (unsigned)a.n_blocks_n);
     const int b = tile_all / a.tiles_per_image;
     const int tile = tile_all % a.tiles_per_image;
-    const int y0 = (tile / a.tiles_x) * 16, x0 = (tile % a.tiles_x) * 32;      // pair mode: b counts pairs, y0 = 0
+    const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * 32;      // pair mode: b counts pairs, y0 = 0
     const int nK = a.cin / kCK;
     const int pair = a.pair;
 
@@ -146,9 +160,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     floatx4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE != 1) bias4 = *reinterpret_cast<const floatx4*>(a.bias + co0);          // bias is padded to cout_pad
 
-    floatx16 acc[MODE == 3 ? 1 : 9];
-    floatx4 acc3[MODE == 3 ? 36 : 1];           // MODE 3: component f of blocks 16 bh + 4 (lane / 16) + v, channel 16 cq + lane % 16
-    if constexpr (MODE == 3) {
+    floatx16 acc[W3 ? 1 : 9];
+    floatx4 acc3[W3 ? 36 : 1];                  // MODE 3 / 4: component f of blocks 16 bh + 4 (lane / 16) + v, channel 16 cq + lane % 16
+    if constexpr (W3) {
 #pragma unroll
         for (int f = 0; f < 36; ++f)
 #pragma unroll
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
 
     // raw tile: 18 x 34 pixels (rows y0 - 1 .. y0 + 16) x 2 channel quads over the threads.  Pair mode: 20 rows = for each
     // of the two images its 8 rows between two rows of zeros, so that no block reads its neighbour image as padding.
-    constexpr int NRAW = (kRawPx * 2 + 511) / 512;
+    constexpr int NRAW = (RPX * 2 + NT - 1) / NT;
     const int64_t img_floats = (int64_t)a.H * a.W * a.cin;
     const int n_img = pair ? min(2, a.B - 2 * b) : 1;          // a missing second image reads as zeros (range check)
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)b * (pair ? 2 : 1) * img_floats), 0,
@@ -181,14 +195,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     int raw_src[NRAW], raw_dst[NRAW];
 #pragma unroll
     for (int i = 0; i < NRAW; ++i) {
-        const int f = tid + i * 512;
+        const int f = tid + i * NT;
         const int px = f >> 1, q = f & 1;
         const int rr = px / kRawW, gx = x0 - 1 + px % kRawW;
         const int img = (pair && rr >= 10) ? 1 : 0;
         const int gy = pair ? rr - 10 * img - 1 : y0 - 1 + rr;
-        const bool ok = f < kRawPx * 2 && (pair || rr < 18) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const bool ok = f < RPX * 2 && (pair || MODE == 4 || rr < 18) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         raw_src[i] = ok ? ((((img * a.H + gy) * a.W + gx) * a.cin + q * 4) * 4) : (int)0x80000000;
-        raw_dst[i] = (f < kRawPx * 2) ? (px * kRS + q * 4) : kRFloats;
+        raw_dst[i] = (f < RPX * 2) ? (px * kRS + q * 4) : RF;
     }
     auto load_raw = [&](int kc) {
 #pragma unroll
@@ -213,7 +227,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     // pair task and one single task.  The roles are uniform in a wave: the code is specialised per role.
     const int t_p = lane & 3, t_bx = (lane >> 2) & 7, t_bylo = lane >> 5;
     auto transform = [&](int rbase, int ubase) {
-        const int half = wave & 1, role = wave >> 1;       // role 0: rows 1, 2; 1: rows 3, 4; 2: row 0; 3: row 5
+        // role 0: rows 1, 2; 1: rows 3, 4; 2: row 0; 3: row 5.  MODE 4: one half, the four roles over the four waves
+        const int half = (MODE == 4) ? 0 : (wave & 1), role = (MODE == 4) ? wave : (wave >> 1);
         const int by = half * 2 + t_bylo;
         const int m = by * 8 + t_bx;
         const float* src = &lds[rbase + ((by * 4 + (pair ? 2 * (by >> 1) : 0)) * kRawW + t_bx * 4) * kRS + t_p * 2];
@@ -229,12 +244,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
             o[3] = e3 + 2.0f * e4;
             o[4] = e3 - 2.0f * e4;
             o[5] = 4.0f * t[1] + (t[5] - 5.0f * t[3]);
-            if constexpr (MODE == 3) {
-                // MODE 3: components in pairs, U[f / 2][block][channel pair][f % 2][2 channels]: a lane's operands for two
+            if constexpr (W3) {
+                // MODE 3 / 4: components in pairs, U[f / 2][block][channel pair][f % 2][2 channels]: a lane's operands for two
                 // components are one 16-byte read, and a wave's reads tile 1 KB without gaps
-                float* dst3 = &lds[ubase + (i * 3) * (2 * kUC) + m * (2 * kCK) + t_p * 4];
+                float* dst3 = &lds[ubase + (i * 3) * (2 * UC) + m * (2 * kCK) + t_p * 4];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) *reinterpret_cast<floatx2*>(dst3 + (j >> 1) * (2 * kUC) + (j & 1) * 2) = o[j];
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<floatx2*>(dst3 + (j >> 1) * (2 * UC) + (j & 1) * 2) = o[j];
             } else {
                 // U[component][block m][8 channels]; the two 16-byte halves of a block swap places in blocks 8..15 and
                 // 24..31, which makes the MFMA operand reads (16 lanes = 16 blocks, one half) conflict free without padding
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         for (int jj = 0; jj < 3; ++jj) af[jj] = *reinterpret_cast<const float4*>(&lds[ubase + u_src + (g * 6 + jj) * kUC]);
     };
 
-    constexpr int kR0 = 2 * kUFloats, kR1 = 2 * kUFloats + kRBuf;
+    constexpr int kR0 = 2 * UF, kR1 = 2 * UF + RB;
     if constexpr (MODE == 1) {
         // transform only: chunks [nb * chunks_per_group, ...) of this tile -> v
         const int k_lo = nb * a.chunks_per_group, k_hi = min(nK, k_lo + a.chunks_per_group);
@@ -385,8 +400,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
     }       // MODE == 0
 
     // ---- MODE 3: fused, every wave owns all 36 components of 16 blocks x 16 channels (see the kernel's header)
-    if constexpr (MODE == 3) {
-        const int bh = wave & 1, cq = wave >> 1;          // half of the tile's blocks, quarter of the 64 channels
+    if constexpr (W3) {
+        const int bh = (MODE == 4) ? 0 : (wave & 1), cq = (MODE == 4) ? wave : (wave >> 1);      // half of the tile's blocks (MODE 3), quarter of the 64 channels
         const int l16 = lane & 15, q = lane >> 4;
         // Filter slab of MODE 3: [chunk][f2 = 0..17][cq][lane][4 floats] = components 2 f2, 2 f2 + 1 x input channels
         // 2 q, 2 q + 1 of the chunk, for output channel 16 cq + lane % 16: one 16-byte load feeds four MFMAs.
@@ -420,8 +435,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         const int u3 = (16 * bh + l16) * (2 * kCK) + 4 * q;
         auto chunk3 = [&](int kc, auto parity) {
             constexpr int P = decltype(parity)::value;
-            constexpr int ucur = P * kUFloats, unxt = (1 - P) * kUFloats;
-            constexpr int rnxt = kR0 + (1 - P) * kRBuf, rfill = kR0 + P * kRBuf;
+            constexpr int ucur = P * UF, unxt = (1 - P) * UF;
+            constexpr int rnxt = kR0 + (1 - P) * RB, rfill = kR0 + P * RB;
             const int kn = min(kc + 1, nK - 1);
             if (kc + 1 < nK) {                          // uniform
                 transform(rnxt, unxt);
@@ -432,12 +447,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
             const float* ub = &lds[ucur + u3];
             float4 a4[2][2];                            // operands of a group of 4 components, read one group ahead
 #pragma unroll
-            for (int c = 0; c < 2; ++c) a4[0][c] = *reinterpret_cast<const float4*>(ub + c * (2 * kUC));
+            for (int c = 0; c < 2; ++c) a4[0][c] = *reinterpret_cast<const float4*>(ub + c * (2 * UC));
 #pragma unroll
             for (int g = 0; g < 9; ++g) {
                 if (g + 1 < 9) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) a4[(g + 1) & 1][c] = *reinterpret_cast<const float4*>(ub + (2 * (g + 1) + c) * (2 * kUC));
+                    for (int c = 0; c < 2; ++c) a4[(g + 1) & 1][c] = *reinterpret_cast<const float4*>(ub + (2 * (g + 1) + c) * (2 * UC));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const floatx2 av[4] = {floatx2{a4[g & 1][0].x, a4[g & 1][0].y}, floatx2{a4[g & 1][0].z, a4[g & 1][0].w},
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         // LDS once (every wave has passed the loop's last barrier: the loop's buffers are free), one barrier, 16-byte stores.
         // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].
         constexpr int PW = (POOL == 1) ? 2 : 4, PH = (POOL == 0) ? 4 : 2;      // outputs a block keeps after pooling
-        constexpr int kTW = 8 * PW, kTH = 4 * PH;                              // the tile after pooling
+        constexpr int kTW = 8 * PW, kTH = (NBLK / 8) * PH;                     // the tile after pooling
         auto at4 = [](float m0, float m1, float m2, float m3, float m4, float m5, float (&o)[4]) {
             const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
             o[0] = (m0 + s1) + s2;
@@ -516,8 +531,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         const int Ho3 = (POOL == 0) ? a.H : a.H / 2, Wo3 = (POOL == 1) ? a.W / 2 : a.W;
         const int ox0 = (POOL == 1) ? (x0 >> 1) : x0;
 #pragma unroll 4
-        for (int it = 0; it < kTW * kTH / 32; ++it) {
-            const int px = (tid >> 4) + it * 32;
+        for (int it = 0; it < kTW * kTH / (NT / 16); ++it) {
+            const int px = (tid >> 4) + it * (NT / 16);
             const int py = px / kTW, pxx = px % kTW;
             const int by = py / PH, bx = pxx / PW;
             const int ob = pair ? 2 * b + (by >> 1) : b;                   // image of this block row
@@ -548,7 +563,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
         return;
     }
 
-    if constexpr (MODE != 3) {
+    if constexpr (!W3) {
     // ---- inverse transform and output, one block row (4 x 32 outputs) at a time.  Register v of a lane belongs to block
     // m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5), i.e. block row v >> 2, and to output channel lane & 31 of the wave's 32.
     // The wave's 3x3 components contribute
@@ -637,7 +652,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_f32_kernel(const Wino4Args 
             }
         }
     }
-    }       // MODE != 3
+    }       // !W3
 }
 
 }  // namespace
@@ -668,7 +683,7 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
         }
     OCR_TRY(L.w_wino4.reserve(w.size() * sizeof(float)));
     OCR_HIP_CHECK(hipMemcpy(L.w_wino4.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (cin < kWaveTileMaxCin) {
+    if (cin < kSplitMinCin) {
         // the same transformed filters in the layout of MODE 3 (shallow layers):
         // [n block][k chunk][f2 = f / 2][cq][lane = 16 q + j][t = 2 (f % 2) + step]: output channel 64 nblock + 16 cq + j,
         // input channel 8 kchunk + 2 q + step
@@ -693,8 +708,9 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
 // Whether the F(4x4,3x3) kernel serves this launch (16 x 32 tiles reasonably full; maps of 8 rows go in pairs).
 bool conv_wino4_fits(const ConvLayer& L, int H, int W, int pool) {
     if (!L.w_wino4.ptr || (int64_t)H * W * L.cin * 4 >= (1ll << 31)) return false;
-    if (H == 8) return (double)W / ((W + 31) / 32 * 32) >= 0.7;          // two images stacked per tile
-    const double fill = (double)H * W / ((double)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32));
+    if (H == 8) return (double)W / ((W + 31) / 32 * 32) >= 0.7;          // one half tile, or two images stacked per tile
+    const int th = (L.w_wino4b.ptr && wino4_wave_tiles() >= 2) ? 8 : 16;  // rows of the tiles the launch will use
+    const double fill = (double)H * W / ((double)((H + th - 1) / th * th) * ((W + 31) / 32 * 32));
     return fill >= 0.7;
 }
 
@@ -723,11 +739,11 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     OCR_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lds_opt_in_lock(lds_opt_in_mutex);
     bool& lds_opt_in = lds_opt_in_dev[dev & 63];
-#define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2) X(0, 3) X(1, 3) X(2, 3)
+#define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2) X(0, 3) X(1, 3) X(2, 3) X(0, 4) X(1, 4) X(2, 4)
     if (!lds_opt_in) {
 #define OCR_W4_OPT_IN(P, M)                                                                                               \
     OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<P, M>),                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, M == 4 ? kLdsBytes4 : kLdsBytes));
         OCR_W4_FOR_ALL(OCR_W4_OPT_IN)
 #undef OCR_W4_OPT_IN
         lds_opt_in = true;
@@ -739,9 +755,20 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     const int64_t v_bytes = tiles_total * nK * kUFloats * 4;
     int mode = 0;
     if (ws && wino4_split() && L.cin >= kSplitMinCin && v_bytes <= (6ll << 30) && ws->reserve((size_t)v_bytes) == OCRHIP_OK) mode = 2;
-    if (mode == 0 && L.w_wino4b.ptr && wino4_wave_tiles()) {      // shallow layer: every wave owns whole (block, channel) tiles
+    int64_t wgs_launch = wgs;
+    // fused layers: every wave owns whole (block, channel) tiles - of half a tile with two workgroups per CU (2, the
+    // default), or of a full tile where there are fewer than 256 input channels (1)
+    const int wt = wino4_wave_tiles();
+    if (mode == 0 && L.w_wino4b.ptr && (wt >= 2 || (wt == 1 && L.cin < kWaveTileMaxCin))) {
         mode = 3;
         a.w = L.w_wino4b.as<float>();
+        if (wt >= 2) {
+            mode = 4;
+            a.pair = 0;
+            a.tiles_per_image = a.tiles_x * ((H + 7) / 8);
+            wgs_launch = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
+            OCR_REQUIRE(wgs_launch < (1ll << 31), "conv_wino4: too many workgroups");
+        }
     }
     a.v = mode == 2 ? ws->as<float>() : nullptr;
     a.chunks_per_group = 8;
@@ -759,14 +786,15 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     char pname[64];
     static const bool per_layer = getenv("OCRHIP_PROFILE_LAYERS") != nullptr;      // development aid: one profile line per layer shape
     if (per_layer)
-        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<p%d,c%d-%d,h%d>", mode == 2 ? "_mul" : (mode == 3 ? "_w" : ""), pool, L.cin, L.cout, H);
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<p%d,c%d-%d,h%d>", mode == 2 ? "_mul" : (mode == 3 ? "_w" : (mode == 4 ? "_h" : "")), pool, L.cin, L.cout, H);
     else
-        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<n64,pool%d,tile16x32>", mode == 2 ? "_mul" : (mode == 3 ? "_w" : ""), pool);
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<n64,pool%d,tile%dx32>", mode == 2 ? "_mul" : (mode == 3 ? "_w" : (mode == 4 ? "_h" : "")), pool, mode == 4 ? 8 : 16);
     ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
                    4.0 * ((mode == 2 ? 0.0 : out_px * L.cin) + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout) + (mode == 2 ? (double)v_bytes : 0.0), s);
 #define OCR_W4_LAUNCH(P, M)                                                                                               \
     if (pool == P && mode == M && M != 1)                                                                                 \
-        hipLaunchKernelGGL((conv_wino4_f32_kernel<P, M>), dim3((unsigned)wgs), dim3(512), kLdsBytes, s, a);
+        hipLaunchKernelGGL((conv_wino4_f32_kernel<P, M>), dim3((unsigned)wgs_launch), dim3(M == 4 ? 256 : 512),           \
+                           M == 4 ? kLdsBytes4 : kLdsBytes, s, a);
     OCR_W4_FOR_ALL(OCR_W4_LAUNCH)
 #undef OCR_W4_LAUNCH
 #undef OCR_W4_FOR_ALL
