@@ -233,7 +233,7 @@ def test_lstm_handover_timeout_is_an_error_not_output(ctx):
     np.testing.assert_array_equal(again, good)
 
 
-@pytest.mark.parametrize('shape', [(2, 128, 224, 3), (1, 96, 160, 3)])
+@pytest.mark.parametrize('shape', [(2, 128, 224, 3), (1, 96, 160, 3), (1, 224, 256, 3)])
 def test_direct_3x3_path_matches_oracle_too(ctx, shape):
     """`conv3x3_winograd`: 2 (default) Winograd F(4x4,3x3) where the maps fill its 16x32 tiles and F(2x2,3x3) elsewhere,
     1 F(2x2,3x3) everywhere, 0 the 3x3 layers as a direct implicit GEMM.  All three agree with the oracle to the
@@ -242,7 +242,8 @@ def test_direct_3x3_path_matches_oracle_too(ctx, shape):
     ctx.east_load_weights(params)
     rng = np.random.default_rng(77)
     # (128, 224): 128x224 and 64x112 maps take the 4x4 kernel, the second with a half-empty last tile column;
-    # (96, 160): 96x160 and 48x80 maps, the second with partial tiles in both directions
+    # (96, 160): 96x160 and 48x80 maps, the second with partial tiles in both directions;
+    # (224, 256): maps of 28 and 14 rows end in a half tile (8 rows) with 4 and 6 valid rows, pooled and unpooled
     img = rng.integers(0, 256, shape, dtype=np.uint8)
     ref = nets.east_forward(params, np.stack([oimg.prepare_east_input(i) for i in img])).numpy()
     cp = nets.init_crnn_params(vocab_size=97, seed=2)
