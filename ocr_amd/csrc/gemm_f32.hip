@@ -47,6 +47,7 @@ struct GemmArgs {
     // A addressing: row m = (b * Hc + r) * Wc + c  ->  base ((b * H + r) * W + c) * cin; k -> (k / seg_len) * seg_stride + k % seg_len
     int Hc, Wc, H, W, cin;
     int seg_len, seg_stride;
+    int64_t x_elems;         // floats in x: where its buffer descriptors end
 };
 
 template <bool ARGMAX>
@@ -67,20 +68,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
     const int64_t m0 = (int64_t)(work / (unsigned)a.n_blocks) * kBM;
     const int nK = a.K / kCK;
 
-    // the 4 rows this thread stages (row = tid / 4 + 64 i, 16-byte column tid % 4)
-    int64_t abase[4];
+    // the 4 rows this thread stages (row = tid / 4 + 64 i, 16-byte column tid % 4).  Loads and stores go through buffer
+    // descriptors that start at the tile's first row (so that 32-bit offsets do for any size of x and y): a per-lane
+    // byte offset that never changes, the k chunk / output row as a scalar offset, and the range check instead of
+    // guards - rows beyond M carry an offset of 2^31: their loads return zeros and their stores are dropped.
+    auto row_offset = [&](int64_t m) {                         // element offset of the A row of output row m (M < 2^31)
+        const unsigned mu = (unsigned)m;
+        const unsigned c = mu % (unsigned)a.Wc, br = mu / (unsigned)a.Wc;
+        const unsigned r = br % (unsigned)a.Hc, b = br / (unsigned)a.Hc;
+        return (((int64_t)b * a.H + r) * a.W + c) * a.cin;
+    };
+    const int64_t x_first = row_offset(m0);
+    const int64_t x_left = (a.x_elems - x_first) * 4;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + x_first), 0, (int)(x_left < 0x7fffffffll ? x_left : 0x7fffffffll), 0x00020000);
+    int abase[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = m0 + (tid >> 2) + 64 * i;
-        if (m < a.M) {
-            const int c = (int)(m % a.Wc);
-            const int64_t br = m / a.Wc;
-            const int r = (int)(br % a.Hc);
-            const int64_t b = br / a.Hc;
-            abase[i] = (((b * a.H + r) * a.W) + c) * (int64_t)a.cin + (tid & 3) * 4;
-        } else {
-            abase[i] = -1;
-        }
+        abase[i] = (m < a.M) ? (int)((row_offset(m) - x_first + (tid & 3) * 4) * 4) : (int)0x80000000;
     }
     const float* wslab = a.w + (int64_t)nb * nK * kBFloats;
 
@@ -104,10 +110,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
         rb0 = src[tid];
         rb1 = src[tid + 256];
         const int k0 = kc * kCK;
-        const int64_t koff = (int64_t)(k0 / a.seg_len) * a.seg_stride + k0 % a.seg_len;
+        const int koff = ((k0 / a.seg_len) * a.seg_stride + k0 % a.seg_len) * 4;      // uniform: a scalar offset
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            ra[i] = (abase[i] >= 0) ? *reinterpret_cast<const float4*>(a.x + abase[i] + koff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, abase[i], koff, 0));
     };
     auto store_chunk = [&](int buf) {
         reinterpret_cast<float4*>(Bs[buf])[tid] = rb0;
@@ -156,22 +162,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
     }
 
     // accumulator register v of a lane: row (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5) of its 32-row tile, column lane & 31
+    // Stores: the lane's offset within the wave's 64 x 128 part of the tile is one VGPR for the whole epilogue; the row
+    // (r, v) and the column tile nt go into the scalar offset, which costs no vector instruction.  The range check of a
+    // buffer access looks at the vector offset only, so in a tile that crosses the end of the rows or of the columns the
+    // lanes that must not write get the out-of-range offset 2^31 per store.
     const bool full = (m0 + kBM <= a.M) && ((nb + 1) * kBN <= a.N);      // uniform: no guards on the stores
     auto write_out = [&](auto guarded) {
+        const int64_t row0 = m0 + wave * 64;                             // descriptor from the wave's first row: 32-bit offsets do
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + row0 * a.N), 0, 0x7fffffff, 0x00020000);
+        const int row_bytes = a.N * 4;
+        const int lane_off = (4 * lh) * row_bytes + (nb * kBN + li) * 4;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int co = nb * kBN + nt * 32 + li;
-            const bool co_ok = co < a.N;
+            const bool co_ok = nb * kBN + nt * 32 + li < a.N;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const int64_t mrow = m0 + wave * 64 + r * 32 + 4 * lh;
-                float* yrow = a.y + mrow * a.N + co;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int dm = (v & 3) + 8 * (v >> 2);
                     float o = acc[r][nt][v] + biasv[nt];
                     if (a.relu) o = fmaxf(o, 0.0f);
-                    if (!decltype(guarded)::value || (co_ok && mrow + dm < a.M)) yrow[(int64_t)dm * a.N] = o;
+                    const bool ok = !decltype(guarded)::value || (co_ok && row0 + r * 32 + 4 * lh + dm < a.M);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), y_rsrc, ok ? lane_off : (int)0x80000000,
+                                                          (r * 32 + dm) * row_bytes + nt * 128, 0);
                 }
             }
         }
@@ -250,7 +263,9 @@ int launch_gemm_f32(const ConvLayer& L, const float* x, float* y, int B, int H, 
     a.M = (int64_t)B * a.Hc * a.Wc;
     a.seg_len = L.ks * L.cin;             // one kernel row: ks pixels of cin channels, contiguous in NHWC
     a.seg_stride = W * L.cin;
-    OCR_REQUIRE((int64_t)B * H * W * L.cin < (1ll << 40), "gemm_f32: input too large");
+    a.x_elems = (int64_t)B * H * W * L.cin;
+    OCR_REQUIRE((int64_t)B * H * W * L.cin < (1ll << 40) && a.M < (1ll << 31), "gemm_f32: input too large");
+    OCR_REQUIRE((int64_t)(64 + 40) * a.N * 4 < (1ll << 31), "gemm_f32: N=%d too wide", a.N);          // a wave's store offsets are 32-bit
     const int64_t wgs = (a.M + kBM - 1) / kBM * a.n_blocks;
     OCR_REQUIRE(wgs < (1ll << 31), "gemm_f32: too many workgroups");
     char pname[64];
@@ -273,7 +288,7 @@ int launch_gemm_f32_argmax(const ConvLayer& L, const float* x, int64_t M, float*
     a.N = L.cout; a.K = L.cin; a.relu = 0;
     a.n_blocks = gemm_f32_column_blocks(L);
     a.H = 1; a.W = (int)M; a.cin = L.cin; a.Hc = 1; a.Wc = (int)M; a.M = M;
-    a.seg_len = L.cin; a.seg_stride = (int)M * L.cin;
+    a.seg_len = L.cin; a.seg_stride = (int)M * L.cin; a.x_elems = M * L.cin;
     const int64_t wgs = (a.M + kBM - 1) / kBM * a.n_blocks;
     OCR_REQUIRE(wgs < (1ll << 31), "gemm_f32_argmax: too many workgroups");
     ProfScope prof("gemm_f32_argmax<tile256x128>", 2.0 * (double)a.M * a.N * a.K,
