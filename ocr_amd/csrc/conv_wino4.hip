@@ -530,6 +530,40 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
         const bool vec3 = (a.cout & 3) == 0 && co0 + 3 < a.cout;
         const int Ho3 = (POOL == 0) ? a.H : a.H / 2, Wo3 = (POOL == 1) ? a.W / 2 : a.W;
         const int ox0 = (POOL == 1) ? (x0 >> 1) : x0;
+        if (MODE == 4 && (a.cout & 3) == 0) {        // uniform (MODE 4 has no image pairs; MODE 3 keeps the plain loop below)
+            // Every store of a lane is (its pixel of the first 16 or 32 staged ones) + (a step that only depends on the
+            // iteration): the lane's byte offset is ONE register for the whole pass, the step goes into the scalar offset
+            // of a buffer store, and pixels or channels outside the map get the out-of-range offset 2^31 instead of a
+            // branch (the range check looks at the vector offset only).  No 64-bit index arithmetic per store.
+            constexpr int PXI = NT / 16;                                          // pixels per iteration
+            constexpr int NIT = kTW * kTH / PXI;
+            const int lp = tid >> 4, ly = lp / kTW, lx = lp % kTW;
+            const int Y0 = (POOL == 0) ? y0 : (y0 >> 1);
+            const int64_t first = (((int64_t)b * Ho3 + Y0) * Wo3 + ox0) * a.cout + nb * 64;      // the tile's first pixel, the block's first channel
+            const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + first), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((POOL == 0 && a.res) ? a.res + first : a.y), 0, (POOL == 0 && a.res) ? 0x7fffffff : 0, 0x00020000);
+            const int pix_bytes = a.cout * 4, row_bytes = Wo3 * pix_bytes;
+            const int lane_off = ly * row_bytes + lx * pix_bytes + c4 * 16;
+            const bool ch_ok = co0 + 3 < a.cout;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int py_it = (it * PXI) / kTW, px_it = (it * PXI) % kTW;     // constants after unrolling
+                const int py = py_it + ly, pxx = px_it + lx;
+                const int by = py / PH, bx = pxx / PW;
+                const bool ok = ch_ok && Y0 + py < Ho3 && ox0 + pxx < Wo3;
+                const int voff = ok ? lane_off : (int)0x80000000;
+                const int soff = py_it * row_bytes + px_it * pix_bytes;
+                const int rot = 16 * ((bx >> 2) & 1) + 32 * (by & 1);
+                floatx4 val = *reinterpret_cast<const floatx4*>(&lds[(lp + it * PXI) * kOS + ((c4 * 4 + rot) & 63)]) + bias4;
+                if (POOL == 0 && a.res) val += __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff, soff, 0));
+                if (a.relu) {
+                    val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, val), y_rsrc, voff, soff, 0);
+            }
+            return;
+        }
 #pragma unroll 4
         for (int it = 0; it < kTW * kTH / (NT / 16); ++it) {
             const int px = (tid >> 4) + it * (NT / 16);
