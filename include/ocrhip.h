@@ -82,12 +82,12 @@ int ocrhip_destroy(ocrhip_handle h);
  *   input tiles once into a workspace, then multiply from it); 0 keeps them fused (every 64-channel workgroup transforms
  *   its tile itself).  Same arithmetic, identical results.
  *   "wino4_wave_tiles": how the fused F(4x4,3x3) launches (fewer than 512 input channels, or all with wino4_split = 0)
- *   divide a tile between the waves.  2 (default) and 1 give every wave whole (block, channel) tiles (16x16x4 matrix
- *   instructions, all 36 Winograd components in one lane), so the inverse transform and the max-pool run in registers and
- *   a tile passes one barrier on its way out: 2 on tiles of 8 x 32 outputs with two workgroups of 4 waves per compute
- *   unit, 1 on tiles of 16 x 32 with one workgroup of 8 waves (only below 256 input channels; 0 above); bit-identical
- *   results.  0: waves own 3x3 of the components and sum their partial outputs through LDS: same arithmetic up to the
- *   order of the inverse transform's additions (all within the 1e-4 tolerance of the parity tests).
+ *   divide a tile between the waves.  1 (default): tiles of 8 x 32 outputs, two workgroups of 4 waves per compute unit,
+ *   every wave owns whole (block, channel) tiles (16x16x4 matrix instructions, all 36 Winograd components in one lane),
+ *   so the inverse transform and the max-pool run in registers and a tile passes one barrier on its way out.  0: tiles
+ *   of 16 x 32, one workgroup of 8 waves, waves own 3x3 of the components and sum their partial outputs through LDS.
+ *   Same arithmetic up to the order of the inverse transform's additions (both within the 1e-4 tolerance of the parity
+ *   tests).
  *   "flat_gemm": 1 (default) runs the Dense layers, the LSTM input projections and the 2x2 convolutions as a flat
  *   GEMM with 256 x 128 tiles; 0 runs them on the implicit-GEMM convolution kernel (256 x 64 / spatial tiles).  Same
  *   arithmetic (a float32 fma chain over k in both).

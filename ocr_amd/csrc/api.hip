@@ -47,7 +47,7 @@ static thread_local int g_wino4_split = 1;
 int wino4_split() { return g_wino4_split; }
 void set_wino4_split(int on) { g_wino4_split = on; }
 static thread_local int g_fuse_ctc = 1;
-static thread_local int g_wino4_wave_tiles = 2;
+static thread_local int g_wino4_wave_tiles = 1;
 int wino4_wave_tiles() { return g_wino4_wave_tiles; }
 void set_wino4_wave_tiles(int on) { g_wino4_wave_tiles = on; }
 static thread_local int g_flat_gemm = 1;
@@ -948,7 +948,7 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "wino4_wave_tiles") == 0) {
-        OCR_REQUIRE(value >= 0 && value <= 2, "set_option: wino4_wave_tiles is 0, 1 or 2");
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: wino4_wave_tiles is 0 or 1");
         h->wino4_wave_tiles = value;
         return OCRHIP_OK;
     }

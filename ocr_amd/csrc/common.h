@@ -153,7 +153,7 @@ struct ocrhip_ctx {
     int lstm_debug_drop = 0;       // test hook: the persistent recurrence withholds one hand-over and times out quickly
     int lstm_persistent = 1;       // recurrence of a BiLSTM layer in one persistent launch (1) or one launch per step (0)
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
-    int wino4_wave_tiles = 2;      // fused F(4x4,3x3) layers: waves own whole (block, channel) tiles, inverse transform in registers - of half a tile, two workgroups per CU (2), of a full tile below 256 input channels (1) - or the 3x3-component split with staged partial sums (0)
+    int wino4_wave_tiles = 1;      // fused F(4x4,3x3) layers: waves own whole (block, channel) tiles of 8 x 32 outputs, inverse transform in registers, two workgroups per CU (1), or the 3x3-component split with staged partial sums on 16 x 32 tiles (0)
     int wino4_split = 1;           // F(4x4,3x3) layers with >= 512 input channels: transform once into `wino_ws`, multiply from it (1) or fused (0)
     ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
     int fuse_ctc = 1;              // tokens without a logits request: class layer reduced to per-block maxima in its epilogue (1) or logits written and re-read (0)

@@ -53,13 +53,12 @@ constexpr int kOS = 64 + 4;                     // floats per staged output pixe
 constexpr int kPartFloats = 128 * kOS;          // one wave group's share of a block row (4 x 32 pixels x 64 channels)
 constexpr int kStageFloats = 4 * kPartFloats;
 constexpr int kLdsBytes = 4 * (kLoopFloats > kStageFloats ? kLoopFloats : kStageFloats);
-// MODE 4 (half tiles): two U of 16 blocks and two raw tiles of 10 rows; or the staged 8 x 32 output tile
-constexpr int kLoopFloats4 = 2 * (36 * 16 * kCK) + 2 * (kRawW * 10 * kRS + 4);
-constexpr int kStageFloats4 = 8 * 32 * kOS;
-constexpr int kLdsBytes4 = 4 * (kLoopFloats4 > kStageFloats4 ? kLoopFloats4 : kStageFloats4);
+// MODE 3 (half tiles): two U of 16 blocks and two raw tiles of 10 rows; or the staged 8 x 32 output tile
+constexpr int kLoopFloats3 = 2 * (36 * 16 * kCK) + 2 * (kRawW * 10 * kRS + 4);
+constexpr int kStageFloats3 = 8 * 32 * kOS;
+constexpr int kLdsBytes3 = 4 * (kLoopFloats3 > kStageFloats3 ? kLoopFloats3 : kStageFloats3);
 constexpr int kWChunkFloats = 36 * 2 * 64 * 4;  // transformed filters of one chunk of one 64-channel block
 constexpr int kSplitMinCin = 512;               // layers at least this deep run as transform kernel + multiply kernel
-constexpr int kWaveTileMaxCin = 256;            // wino4_wave_tiles = 1: fused layers shallower than this run MODE 3 (few chunks: the cheap epilogue pays), the others MODE 0 (half the operand loads per MFMA)
 
 struct Wino4Args {
     const float* x;        // (B,H,W,cin)
@@ -114,28 +113,27 @@ __device__ __forceinline__ void inverse_part(const float (&M)[3][3], float (&Y)[
 //   MODE 2 multiplies only: the MFMA operands of both sides come straight from memory (v and the filter slab, 16 bytes
 //          per lane, reloaded for the next chunk right after their last use): no LDS, no barrier and no vector-ALU work
 //          in the chunk loop; LDS serves the epilogue alone.
-//   MODE 3 is the fused kernel with a different division of the work between the waves, used for the shallow layers
-//          (< 256 input channels: few chunks, so the epilogue weighs most).  The multiplications run on
-//          v_mfma_f32_16x16x4_f32 and wave (bh, cq) owns ALL 36 components of 16 blocks x 16 channels (36 accumulators of
-//          4 registers: the same 144).  A lane then holds the complete 6x6 product of its (block, channel) elements: the
-//          inverse transform and the max-pool happen in registers, the workgroup stages its (pooled) tile in LDS once
-//          and passes ONE barrier before the 16-byte stores - against four partial sums per output, staged one block
-//          row at a time between eight barriers, in MODE 0.  The price: a block's transformed data is read from LDS by
-//          four waves instead of two, and a filter fragment is loaded by two waves instead of one (both have room).
-//          Same arithmetic as MODE 0 up to the order of the additions in the inverse transform.
-//   MODE 4 is MODE 3 on half a tile: a workgroup of 4 waves computes 8 x 32 outputs (2 x 8 blocks) x 64 channels, wave
-//          cq owns all 36 components of its 16 blocks x 16 channels.  Same instructions per wave and per output as
-//          MODE 3, but half the LDS, so TWO workgroups share a CU: while one waits (first loads of a tile, its barriers,
-//          the stores of its epilogue) the other one's waves issue.  Maps of 8 rows are one tile per image.
+//   MODE 3 is the fused kernel with a different division of the work between the waves; it serves every fused launch
+//          by default (MODE 0 remains for `wino4_wave_tiles = 0` and under MODE 2).  A workgroup of 4 waves computes 8 x 32
+//          outputs (2 x 8 blocks of 4x4) x 64 channels; the multiplications run on v_mfma_f32_16x16x4_f32 and wave cq owns
+//          ALL 36 components of the 16 blocks x 16 channels (36 accumulators of 4 registers: the same 144).  A lane then
+//          holds the complete 6x6 product of its (block, channel) elements: the inverse transform and the max-pool
+//          happen in registers, the workgroup stages its (pooled) tile in LDS once and passes ONE barrier before the
+//          16-byte stores - against four partial sums per output, staged one block row at a time between eight barriers,
+//          in MODE 0.  The price: a block's transformed data is read from LDS by four waves instead of two (36 16-byte
+//          operand reads per wave and chunk against 27).  Half the tile of MODE 0 means half the LDS (64 KB in the loop,
+//          70 KB for the staged output), so TWO workgroups share a CU, one wave of each per SIMD: while one waits (first
+//          loads of a tile, a barrier, the stores of its epilogue) the other one's waves issue.  Maps of 8 rows are one
+//          tile per image.  Same arithmetic as MODE 0 up to the order of the additions in the inverse transform.
 template <int POOL, int MODE>
-__global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv_wino4_f32_kernel(const Wino4Args a) {
+__global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv_wino4_f32_kernel(const Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // U[2] then raw[2]: chunk j lives in buffer j & 1
-    constexpr bool W3 = (MODE == 3 || MODE == 4);          // the variants whose waves own whole (block, channel) tiles
-    constexpr int NT = (MODE == 4) ? 256 : 512;            // threads
-    constexpr int NBLK = (MODE == 4) ? 16 : 32;            // 4x4 blocks of a workgroup's tile
+    constexpr bool W3 = (MODE == 3);                       // the variant whose waves own whole (block, channel) tiles
+    constexpr int NT = W3 ? 256 : 512;                     // threads
+    constexpr int NBLK = W3 ? 16 : 32;                     // 4x4 blocks of a workgroup's tile
     constexpr int TH = NBLK / 2;                           // output rows of the tile
     constexpr int UC = NBLK * kCK, UF = 36 * UC;           // floats per component of U, per U
-    constexpr int RH = (MODE == 4) ? 10 : kRawH, RPX = kRawW * RH, RF = RPX * kRS, RB = RF + 4;      // raw tile
+    constexpr int RH = W3 ? 10 : kRawH, RPX = kRawW * RH, RF = RPX * kRS, RB = RF + 4;      // raw tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,7 +159,7 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
     if constexpr (MODE != 1) bias4 = *reinterpret_cast<const floatx4*>(a.bias + co0);          // bias is padded to cout_pad
 
     floatx16 acc[W3 ? 1 : 9];
-    floatx4 acc3[W3 ? 36 : 1];                  // MODE 3 / 4: component f of blocks 16 bh + 4 (lane / 16) + v, channel 16 cq + lane % 16
+    floatx4 acc3[W3 ? 36 : 1];                  // MODE 3: component f of blocks 4 (lane / 16) + v, channel 16 cq + lane % 16
     if constexpr (W3) {
 #pragma unroll
         for (int f = 0; f < 36; ++f)
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
         const int rr = px / kRawW, gx = x0 - 1 + px % kRawW;
         const int img = (pair && rr >= 10) ? 1 : 0;
         const int gy = pair ? rr - 10 * img - 1 : y0 - 1 + rr;
-        const bool ok = f < RPX * 2 && (pair || MODE == 4 || rr < 18) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const bool ok = f < RPX * 2 && (pair || W3 || rr < 18) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         raw_src[i] = ok ? ((((img * a.H + gy) * a.W + gx) * a.cin + q * 4) * 4) : (int)0x80000000;
         raw_dst[i] = (f < RPX * 2) ? (px * kRS + q * 4) : RF;
     }
@@ -227,8 +225,8 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
     // pair task and one single task.  The roles are uniform in a wave: the code is specialised per role.
     const int t_p = lane & 3, t_bx = (lane >> 2) & 7, t_bylo = lane >> 5;
     auto transform = [&](int rbase, int ubase) {
-        // role 0: rows 1, 2; 1: rows 3, 4; 2: row 0; 3: row 5.  MODE 4: one half, the four roles over the four waves
-        const int half = (MODE == 4) ? 0 : (wave & 1), role = (MODE == 4) ? wave : (wave >> 1);
+        // role 0: rows 1, 2; 1: rows 3, 4; 2: row 0; 3: row 5.  MODE 3: one half, the four roles over the four waves
+        const int half = W3 ? 0 : (wave & 1), role = W3 ? wave : (wave >> 1);
         const int by = half * 2 + t_bylo;
         const int m = by * 8 + t_bx;
         const float* src = &lds[rbase + ((by * 4 + (pair ? 2 * (by >> 1) : 0)) * kRawW + t_bx * 4) * kRS + t_p * 2];
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
             o[4] = e3 - 2.0f * e4;
             o[5] = 4.0f * t[1] + (t[5] - 5.0f * t[3]);
             if constexpr (W3) {
-                // MODE 3 / 4: components in pairs, U[f / 2][block][channel pair][f % 2][2 channels]: a lane's operands for two
+                // MODE 3: components in pairs, U[f / 2][block][channel pair][f % 2][2 channels]: a lane's operands for two
                 // components are one 16-byte read, and a wave's reads tile 1 KB without gaps
                 float* dst3 = &lds[ubase + (i * 3) * (2 * UC) + m * (2 * kCK) + t_p * 4];
 #pragma unroll
@@ -401,7 +399,7 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
 
     // ---- MODE 3: fused, every wave owns all 36 components of 16 blocks x 16 channels (see the kernel's header)
     if constexpr (W3) {
-        const int bh = (MODE == 4) ? 0 : (wave & 1), cq = (MODE == 4) ? wave : (wave >> 1);      // half of the tile's blocks (MODE 3), quarter of the 64 channels
+        const int cq = wave;                              // quarter of the 64 channels
         const int l16 = lane & 15, q = lane >> 4;
         // Filter slab of MODE 3: [chunk][f2 = 0..17][cq][lane][4 floats] = components 2 f2, 2 f2 + 1 x input channels
         // 2 q, 2 q + 1 of the chunk, for output channel 16 cq + lane % 16: one 16-byte load feeds four MFMAs.
@@ -430,9 +428,9 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
         transform(kR0, 0);
         __syncthreads();
 
-        // operands of a lane within a component pair of U: block 16 bh + lane % 16, channels 2 q and 2 q + 1 of both
+        // operands of a lane within a component pair of U: block lane % 16, channels 2 q and 2 q + 1 of both
         // components (k of the two MFMAs that consume the chunk's 8 channels: k = lane / 16, channel = 2 k + step)
-        const int u3 = (16 * bh + l16) * (2 * kCK) + 4 * q;
+        const int u3 = l16 * (2 * kCK) + 4 * q;
         auto chunk3 = [&](int kc, auto parity) {
             constexpr int P = decltype(parity)::value;
             constexpr int ucur = P * UF, unxt = (1 - P) * UF;
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
         const int ch3 = cq * 16 + l16;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int m = 16 * bh + 4 * q + v, by = m >> 3, bx = m & 7;
+            const int m = 4 * q + v, by = m >> 3, bx = m & 7;
             float Wt[6][4];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
@@ -527,10 +525,9 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
                 }
         }
         __syncthreads();
-        const bool vec3 = (a.cout & 3) == 0 && co0 + 3 < a.cout;
         const int Ho3 = (POOL == 0) ? a.H : a.H / 2, Wo3 = (POOL == 1) ? a.W / 2 : a.W;
         const int ox0 = (POOL == 1) ? (x0 >> 1) : x0;
-        if (MODE == 4 && (a.cout & 3) == 0) {        // uniform (MODE 4 has no image pairs; MODE 3 keeps the plain loop below)
+        if ((a.cout & 3) == 0) {                     // uniform
             // Every store of a lane is (its pixel of the first 16 or 32 staged ones) + (a step that only depends on the
             // iteration): the lane's byte offset is ONE register for the whole pass, the step goes into the scalar offset
             // of a buffer store, and pixels or channels outside the map get the out-of-range offset 2^31 instead of a
@@ -564,33 +561,25 @@ __global__ __launch_bounds__(MODE == 4 ? 256 : 512, MODE == 4 ? 2 : 1) void conv
             }
             return;
         }
+        // a channel count that is not a multiple of 4: element by element
 #pragma unroll 4
         for (int it = 0; it < kTW * kTH / (NT / 16); ++it) {
             const int px = (tid >> 4) + it * (NT / 16);
             const int py = px / kTW, pxx = px % kTW;
             const int by = py / PH, bx = pxx / PW;
-            const int ob = pair ? 2 * b + (by >> 1) : b;                   // image of this block row
-            const int yy = (pair ? (by & 1) * PH : ((POOL == 0) ? y0 : (y0 >> 1)) + by * PH) + py % PH, xx = ox0 + pxx;
-            if (ob >= a.B || yy >= Ho3 || xx >= Wo3) continue;
+            const int yy = ((POOL == 0) ? y0 : (y0 >> 1)) + py, xx = ox0 + pxx;
+            if (yy >= Ho3 || xx >= Wo3) continue;
             const int rot = 16 * ((bx >> 2) & 1) + 32 * (by & 1);
-            floatx4 val = *reinterpret_cast<const floatx4*>(&lds[px * kOS + ((c4 * 4 + rot) & 63)]) + bias4;
-            const int64_t idx = (((int64_t)ob * Ho3 + yy) * Wo3 + xx) * a.cout + co0;
-            if (vec3) {
-                if (POOL == 0 && a.res) val += *reinterpret_cast<const floatx4*>(a.res + idx);
-                if (a.relu) {
-                    val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
-                }
-                *reinterpret_cast<floatx4*>(a.y + idx) = val;
-            } else {
-                const float e[4] = {val.x, val.y, val.z, val.w};
+            const floatx4 val = *reinterpret_cast<const floatx4*>(&lds[px * kOS + ((c4 * 4 + rot) & 63)]) + bias4;
+            const int64_t idx = (((int64_t)b * Ho3 + yy) * Wo3 + xx) * a.cout + co0;
+            const float e[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (co0 + k < a.cout) {
-                        float o1 = e[k];
-                        if (POOL == 0 && a.res) o1 += a.res[idx + k];
-                        if (a.relu) o1 = fmaxf(o1, 0.0f);
-                        a.y[idx + k] = o1;
-                    }
+            for (int k = 0; k < 4; ++k) {
+                if (co0 + k < a.cout) {
+                    float o1 = e[k];
+                    if (POOL == 0 && a.res) o1 += a.res[idx + k];
+                    if (a.relu) o1 = fmaxf(o1, 0.0f);
+                    a.y[idx + k] = o1;
                 }
             }
         }
@@ -718,7 +707,7 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
     OCR_TRY(L.w_wino4.reserve(w.size() * sizeof(float)));
     OCR_HIP_CHECK(hipMemcpy(L.w_wino4.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     if (cin < kSplitMinCin) {
-        // the same transformed filters in the layout of MODE 3 (shallow layers):
+        // the same transformed filters in the layout of MODE 3 (the fused layers):
         // [n block][k chunk][f2 = f / 2][cq][lane = 16 q + j][t = 2 (f % 2) + step]: output channel 64 nblock + 16 cq + j,
         // input channel 8 kchunk + 2 q + step
         std::vector<float> w3((size_t)nN * nK * kWChunkFloats, 0.0f);
@@ -743,7 +732,7 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
 bool conv_wino4_fits(const ConvLayer& L, int H, int W, int pool) {
     if (!L.w_wino4.ptr || (int64_t)H * W * L.cin * 4 >= (1ll << 31)) return false;
     if (H == 8) return (double)W / ((W + 31) / 32 * 32) >= 0.7;          // one half tile, or two images stacked per tile
-    const int th = (L.w_wino4b.ptr && wino4_wave_tiles() >= 2) ? 8 : 16;  // rows of the tiles the launch will use
+    const int th = (L.w_wino4b.ptr && wino4_wave_tiles()) ? 8 : 16;       // rows of the tiles the launch will use
     const double fill = (double)H * W / ((double)((H + th - 1) / th * th) * ((W + 31) / 32 * 32));
     return fill >= 0.7;
 }
@@ -773,11 +762,11 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     OCR_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lds_opt_in_lock(lds_opt_in_mutex);
     bool& lds_opt_in = lds_opt_in_dev[dev & 63];
-#define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2) X(0, 3) X(1, 3) X(2, 3) X(0, 4) X(1, 4) X(2, 4)
+#define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2) X(0, 3) X(1, 3) X(2, 3)
     if (!lds_opt_in) {
 #define OCR_W4_OPT_IN(P, M)                                                                                               \
     OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<P, M>),                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, M == 4 ? kLdsBytes4 : kLdsBytes));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, M == 3 ? kLdsBytes3 : kLdsBytes));
         OCR_W4_FOR_ALL(OCR_W4_OPT_IN)
 #undef OCR_W4_OPT_IN
         lds_opt_in = true;
@@ -790,19 +779,14 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     int mode = 0;
     if (ws && wino4_split() && L.cin >= kSplitMinCin && v_bytes <= (6ll << 30) && ws->reserve((size_t)v_bytes) == OCRHIP_OK) mode = 2;
     int64_t wgs_launch = wgs;
-    // fused layers: every wave owns whole (block, channel) tiles - of half a tile with two workgroups per CU (2, the
-    // default), or of a full tile where there are fewer than 256 input channels (1)
-    const int wt = wino4_wave_tiles();
-    if (mode == 0 && L.w_wino4b.ptr && (wt >= 2 || (wt == 1 && L.cin < kWaveTileMaxCin))) {
+    // fused layers: every wave owns whole (block, channel) tiles of half a tile, two workgroups per CU
+    if (mode == 0 && L.w_wino4b.ptr && wino4_wave_tiles()) {
         mode = 3;
         a.w = L.w_wino4b.as<float>();
-        if (wt >= 2) {
-            mode = 4;
-            a.pair = 0;
-            a.tiles_per_image = a.tiles_x * ((H + 7) / 8);
-            wgs_launch = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
-            OCR_REQUIRE(wgs_launch < (1ll << 31), "conv_wino4: too many workgroups");
-        }
+        a.pair = 0;
+        a.tiles_per_image = a.tiles_x * ((H + 7) / 8);
+        wgs_launch = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
+        OCR_REQUIRE(wgs_launch < (1ll << 31), "conv_wino4: too many workgroups");
     }
     a.v = mode == 2 ? ws->as<float>() : nullptr;
     a.chunks_per_group = 8;
@@ -820,15 +804,15 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     char pname[64];
     static const bool per_layer = getenv("OCRHIP_PROFILE_LAYERS") != nullptr;      // development aid: one profile line per layer shape
     if (per_layer)
-        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<p%d,c%d-%d,h%d>", mode == 2 ? "_mul" : (mode == 3 ? "_w" : (mode == 4 ? "_h" : "")), pool, L.cin, L.cout, H);
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<p%d,c%d-%d,h%d>", mode == 2 ? "_mul" : (mode == 3 ? "_h" : ""), pool, L.cin, L.cout, H);
     else
-        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<n64,pool%d,tile%dx32>", mode == 2 ? "_mul" : (mode == 3 ? "_w" : (mode == 4 ? "_h" : "")), pool, mode == 4 ? 8 : 16);
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<n64,pool%d,tile%dx32>", mode == 2 ? "_mul" : (mode == 3 ? "_h" : ""), pool, mode == 3 ? 8 : 16);
     ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
                    4.0 * ((mode == 2 ? 0.0 : out_px * L.cin) + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout) + (mode == 2 ? (double)v_bytes : 0.0), s);
 #define OCR_W4_LAUNCH(P, M)                                                                                               \
     if (pool == P && mode == M && M != 1)                                                                                 \
-        hipLaunchKernelGGL((conv_wino4_f32_kernel<P, M>), dim3((unsigned)wgs_launch), dim3(M == 4 ? 256 : 512),           \
-                           M == 4 ? kLdsBytes4 : kLdsBytes, s, a);
+        hipLaunchKernelGGL((conv_wino4_f32_kernel<P, M>), dim3((unsigned)wgs_launch), dim3(M == 3 ? 256 : 512),           \
+                           M == 3 ? kLdsBytes3 : kLdsBytes, s, a);
     OCR_W4_FOR_ALL(OCR_W4_LAUNCH)
 #undef OCR_W4_LAUNCH
 #undef OCR_W4_FOR_ALL
