@@ -52,9 +52,10 @@ __device__ __forceinline__ float tap_weight(const Axis& a, float center, int lo,
     return (x < 1.0f) ? (1.0f - x) : 0.0f;
 }
 
-__device__ __forceinline__ float gray_at(const uint8_t* __restrict__ img, int W, int y, int x) {
+// `unit` = the 256 values u / 255.0f (a float division is ten instructions; a pixel tap needs three)
+__device__ __forceinline__ float gray_at(const uint8_t* __restrict__ img, const float* __restrict__ unit, int W, int y, int x) {
     const uint8_t* p = img + ((int64_t)y * W + x) * 3;
-    const float r = (float)p[0] / 255.0f, g = (float)p[1] / 255.0f, b = (float)p[2] / 255.0f;
+    const float r = unit[p[0]], g = unit[p[1]], b = unit[p[2]];
     float v = r * 0.2989f;
     v = v + g * 0.5870f;
     v = v + b * 0.1140f;
@@ -69,10 +70,11 @@ __device__ __forceinline__ float gray_at(const uint8_t* __restrict__ img, int W,
 template <bool ROT>
 struct Source {
     const uint8_t* img;
+    const float* unit;      // u / 255.0f for u = 0..255 (LDS)
     int W, H, x0, y0;
     float ox, oy, sxx, sxy, syx, syy;
     __device__ __forceinline__ float at(int y, int x) const {
-        if (!ROT) return gray_at(img, W, y0 + y, x0 + x);
+        if (!ROT) return gray_at(img, unit, W, y0 + y, x0 + x);
         const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
         const float px = (ox + fx * sxx) + fy * syx;
         const float py = (oy + fx * sxy) + fy * syy;
@@ -83,8 +85,8 @@ struct Source {
         const int ix = (int)fminf(fmaxf(flx, -1.0f), (float)W), iy = (int)fminf(fmaxf(fly, -1.0f), (float)H);
         const int xa = min(max(ix, 0), W - 1), xb = min(max(ix + 1, 0), W - 1);
         const int ya = min(max(iy, 0), H - 1), yb = min(max(iy + 1, 0), H - 1);
-        const float top = gray_at(img, W, ya, xa) * (1.0f - tx) + gray_at(img, W, ya, xb) * tx;
-        const float bot = gray_at(img, W, yb, xa) * (1.0f - tx) + gray_at(img, W, yb, xb) * tx;
+        const float top = gray_at(img, unit, W, ya, xa) * (1.0f - tx) + gray_at(img, unit, W, ya, xb) * tx;
+        const float bot = gray_at(img, unit, W, yb, xa) * (1.0f - tx) + gray_at(img, unit, W, yb, xb) * tx;
         return top * (1.0f - ty) + bot * ty;
     }
 };
@@ -121,7 +123,11 @@ __global__ __launch_bounds__(256) void crop_resize_pack_kernel(const uint8_t* __
     const int n = blockIdx.x;
     int b = box_img[n];
     b = min(max(b, 0), B - 1);
+    __shared__ float s_unit[256];
+    s_unit[threadIdx.x] = (float)threadIdx.x / 255.0f;          // 256 threads
+    __syncthreads();
     Source<ROT> src;
+    src.unit = s_unit;
     src.img = img + (int64_t)b * H * W * 3;
     src.W = W;
     src.H = H;
