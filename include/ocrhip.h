@@ -88,6 +88,8 @@ int ocrhip_destroy(ocrhip_handle h);
  *   of 16 x 32, one workgroup of 8 waves, waves own 3x3 of the components and sum their partial outputs through LDS.
  *   Same arithmetic up to the order of the inverse transform's additions (both within the 1e-4 tolerance of the parity
  *   tests).
+ *   "first_layer_mfma": 1 (default) runs the detector's first convolution (3 -> 64 channels) on the matrix cores, 0 on
+ *   the vector ALU; both sum the 27 products of an output in the same order: identical results.
  *   "flat_gemm": 1 (default) runs the Dense layers, the LSTM input projections and the 2x2 convolutions as a flat
  *   GEMM with 256 x 128 tiles; 0 runs them on the implicit-GEMM convolution kernel (256 x 64 / spatial tiles).  Same
  *   arithmetic (a float32 fma chain over k in both).

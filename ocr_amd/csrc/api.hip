@@ -50,6 +50,9 @@ static thread_local int g_fuse_ctc = 1;
 static thread_local int g_wino4_wave_tiles = 1;
 int wino4_wave_tiles() { return g_wino4_wave_tiles; }
 void set_wino4_wave_tiles(int on) { g_wino4_wave_tiles = on; }
+static thread_local int g_first_layer_mfma = 1;
+int first_layer_mfma() { return g_first_layer_mfma; }
+void set_first_layer_mfma(int on) { g_first_layer_mfma = on; }
 static thread_local int g_flat_gemm = 1;
 int flat_gemm() { return g_flat_gemm; }
 void set_flat_gemm(int on) { g_flat_gemm = on; }
@@ -260,6 +263,7 @@ using namespace ocrhip;
         ocrhip::set_current_workspace(&(h)->wino_ws);               \
         ocrhip::set_wino4_split((h)->wino4_split);                  \
         ocrhip::set_wino4_wave_tiles((h)->wino4_wave_tiles);        \
+        ocrhip::set_first_layer_mfma((h)->first_layer_mfma);        \
     } while (0)
 
 extern "C" {
@@ -945,6 +949,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "wino4_split") == 0) {
         OCR_REQUIRE(value == 0 || value == 1, "set_option: wino4_split is 0 or 1");
         h->wino4_split = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "first_layer_mfma") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: first_layer_mfma is 0 or 1");
+        h->first_layer_mfma = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "wino4_wave_tiles") == 0) {

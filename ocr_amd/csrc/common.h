@@ -56,6 +56,20 @@ struct Profiler {
 Profiler* current_profiler();
 void set_current_profiler(Profiler* p);
 
+#if defined(__HIPCC__)
+// 16-byte buffer store whose data registers stay untouched for two more cycles.  The store reads the upper part of its
+// 128-bit data after it has issued; a vector instruction right behind it that overwrites those registers (the compiler
+// likes to reuse them for the next address) changed what reached memory.  The compiler only knows this hazard for stores
+// without a scalar offset register; the s_nop takes the data as an operand, so nothing can be scheduled between the two
+// that writes them.  (Stores of 8 bytes or less are not affected.)
+typedef float ocr_floatx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buffer_store_b128_guarded(ocr_floatx4 data, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, data), rsrc,
+                                           voffset, soffset, 0);
+    asm volatile("s_nop 1" ::"v"(data));
+}
+#endif
+
 // RAII: records an event before and after the launches made in its scope (no-op when disabled).
 struct ProfScope {
     Profiler* p;
@@ -153,6 +167,7 @@ struct ocrhip_ctx {
     int lstm_debug_drop = 0;       // test hook: the persistent recurrence withholds one hand-over and times out quickly
     int lstm_persistent = 1;       // recurrence of a BiLSTM layer in one persistent launch (1) or one launch per step (0)
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
+    int first_layer_mfma = 1;      // the detector's 3 -> 64 first layer on the matrix cores (1) or on the vector ALU (0); identical results
     int wino4_wave_tiles = 1;      // fused F(4x4,3x3) layers: waves own whole (block, channel) tiles of 8 x 32 outputs, inverse transform in registers, two workgroups per CU (1), or the 3x3-component split with staged partial sums on 16 x 32 tiles (0)
     int wino4_split = 1;           // F(4x4,3x3) layers with >= 512 input channels: transform once into `wino_ws`, multiply from it (1) or fused (0)
     ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
@@ -196,6 +211,8 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
 DevBuf* current_workspace();         // grow-only scratch of the handle in use on this thread (transformed tiles), or nullptr
 void set_current_workspace(DevBuf* ws);
 int wino4_wave_tiles();              // option of the handle in use on this thread
+int first_layer_mfma();
+void set_first_layer_mfma(int on);
 void set_wino4_wave_tiles(int on);
 int wino4_split();                   // option of the handle in use on this thread
 void set_wino4_split(int on);

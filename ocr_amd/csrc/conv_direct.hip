@@ -184,6 +184,114 @@ __global__ __launch_bounds__(256) void conv_first_rows_kernel(const void* __rest
     }
 }
 
+// The unpooled 3 -> 64 first layer on the matrix cores.  K = 27 is far too shallow for the tiled kernels (their chunks are
+// 8 or 16 channels deep), but per output the f32 MFMA still does twice the work of a vector fma per cycle: a wave
+// multiplies 32 pixels x 28 (27 + one zero) by 28 x 64 with 2 x 14 v_mfma_f32_32x32x2_f32, the weights held in 28
+// registers for the whole workgroup.  A workgroup owns 8 rows x 64 columns: its 10 x 66 input pixels are normalised once
+// (uint8 input: through the 256-entry table of the reference's float32 results) into LDS, from where a lane reads the 14
+// neighbour values of its pixel that fall on its half of k; each wave turns 32 pixels x 64 channels at a time
+// (4 units of one row half), adds bias, applies ReLU, transposes through its own LDS area (pixel stride 72 floats:
+// conflict free both ways) and stores the 8 KB as 16-byte-per-lane coalesced rows.  Products are exact and summed in
+// float32 like the vector kernel's, in pairs of k instead of one by one.
+typedef float floatx16_cf __attribute__((ext_vector_type(16)));
+
+template <bool U8>
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const void* __restrict__ xin, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int H, int W) {
+    constexpr int ROWS = 8, IW = 66, IN_FLOATS = (ROWS + 2) * IW * 3, TS = 72;
+    __shared__ float s_in[IN_FLOATS + 4];
+    __shared__ __attribute__((aligned(16))) float s_t[4][32 * TS];
+    __shared__ float lut[U8 ? 256 : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, lh = lane >> 5;
+    const int ox0 = blockIdx.x * 64, oy0 = blockIdx.y * ROWS, b = blockIdx.z;
+
+    if (U8) {
+        lut[tid] = (((float)tid / 255.0f) - 0.5f) / 0.5f;
+        __syncthreads();
+    }
+    // input tile: rows oy0 - 1 .. oy0 + 8, columns ox0 - 1 .. ox0 + 64, zero outside the image (the padding of the
+    // normalised tensor); consecutive elements of a row are consecutive in memory
+    for (int e = tid; e < IN_FLOATS; e += 256) {
+        const int r = e / (IW * 3), rem = e % (IW * 3);
+        const int yy = oy0 - 1 + r, xx = ox0 - 1 + rem / 3;
+        float v = 0.0f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const int64_t idx = (((int64_t)b * H + yy) * W + ox0 - 1) * 3 + rem;
+            v = U8 ? lut[reinterpret_cast<const uint8_t*>(xin)[idx]] : reinterpret_cast<const float*>(xin)[idx];
+        }
+        s_in[e] = v;
+    }
+    // weights [k = (ky * 3 + kx) * 3 + c][64]: step s uses k = 2 s + lh, the 28th k is zero
+    float bw[14][2];
+#pragma unroll
+    for (int st = 0; st < 14; ++st) {
+        const int k = 2 * st + lh;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bw[st][nt] = (k < 27) ? w[k * 64 + nt * 32 + m] : 0.0f;
+    }
+    const float bias0 = bias[m], bias1 = bias[32 + m];
+    // LDS offsets of the lane's 14 neighbour values relative to (row r, column half h): k -> (ky, kx, c)
+    int aoff[14];
+#pragma unroll
+    for (int st = 0; st < 14; ++st) {
+        const int k = min(2 * st + lh, 26);
+        aoff[st] = ((k / 9) * IW + (k / 3) % 3 + m) * 3 + k % 3;
+    }
+    __syncthreads();
+
+    // the workgroup's output rows start at the descriptor's base: one lane offset for all stores, the unit in the scalar offset
+    const int64_t first = (((int64_t)b * H + oy0) * W + ox0) * 64;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(y + first), 0, 0x7fffffff, 0x00020000);
+    float* t = s_t[wave];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = wave * 2 + (u >> 1), h = u & 1;              // row of the tile, half of its 64 columns
+        const bool row_ok = oy0 + r < H;                           // uniform per wave
+        const float* src = s_in + (r * IW + h * 32) * 3;
+        floatx16_cf acc0, acc1;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
+        // all 14 operands first, then the 28 matrix instructions back to back
+        float av[14];
+#pragma unroll
+        for (int st = 0; st < 14; ++st) av[st] = src[aoff[st]];
+        av[13] = lh ? 0.0f : av[13];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < 14; ++st) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bw[st][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bw[st][1], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // register v of a lane: pixel (v & 3) + 8 (v >> 2) + 4 lh of the 32, channel m (+ 32)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int px = (v & 3) + 8 * (v >> 2) + 4 * lh;
+            t[px * TS + m] = fmaxf(acc0[v] + bias0, 0.0f);
+            t[px * TS + 32 + m] = fmaxf(acc1[v] + bias1, 0.0f);
+        }
+        // the wave's own transpose: LDS works off a wave's accesses in order, the fences keep the compiler from moving
+        // the 16-byte reads (another type than the float writes) across them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int npx = row_ok ? min(32, W - ox0 - h * 32) : 0;    // valid pixels of this half (<= 0: none)
+        const int unit_off = (r * W + h * 32) * 256;               // bytes from the workgroup's first pixel
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;                           // float4 index within the unit: pixel i / 16, channel quad i % 16
+            const float4 q = *reinterpret_cast<const float4*>(&t[(i >> 4) * TS + (i & 15) * 4]);
+            buffer_store_b128_guarded(ocr_floatx4{q.x, q.y, q.z, q.w}, y_rsrc, (i >> 4) < npx ? i * 16 : (int)0x80000000, unit_off);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // 1x1 heads on the 32-channel merged map: out = sigmoid(W x + b), 6 channels.  w: [6][32].
 __global__ __launch_bounds__(256) void east_heads_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ maps,
@@ -240,7 +348,12 @@ int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y,
                    px * L.cin * (x_is_u8 ? 1.0 : 4.0) + 4.0 * px * L.cout / (pool ? 4.0 : 1.0), s);
     if (L.cin == 3 && L.cout == 64 && pool == 0) {
         dim3 grid((W + 63) / 64, (H + 7) / 8, B), block(256);
-        if (x_is_u8)
+        if (first_layer_mfma() && (int64_t)8 * W * 256 < (1ll << 31)) {
+            if (x_is_u8)
+                hipLaunchKernelGGL(conv_first_mfma_kernel<true>, grid, block, 0, s, x, w, bias, y, H, W);
+            else
+                hipLaunchKernelGGL(conv_first_mfma_kernel<false>, grid, block, 0, s, x, w, bias, y, H, W);
+        } else if (x_is_u8)
             hipLaunchKernelGGL((conv_first_rows_kernel<3, 64, true, 8>), grid, block, 0, s, x, w, bias, y, H, W);
         else
             hipLaunchKernelGGL((conv_first_rows_kernel<3, 64, false, 8>), grid, block, 0, s, x, w, bias, y, H, W);

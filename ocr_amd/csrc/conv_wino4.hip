@@ -557,7 +557,7 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
                 if (a.relu) {
                     val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, val), y_rsrc, voff, soff, 0);
+                buffer_store_b128_guarded(val, y_rsrc, voff, soff);
             }
             return;
         }

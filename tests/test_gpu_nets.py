@@ -359,3 +359,27 @@ def test_bf16_variant_within_1e2_of_the_float32_oracle(ctx):
     a = ctx.crnn_forward_packed(packed, widths, want_logits=True, compute_dtype=BF16)['logits'].cpu().numpy()
     b = ctx.crnn_forward_packed(packed, widths, want_logits=True)['logits'].cpu().numpy()
     assert rel(a, b) <= 1e-2, rel(a, b)
+
+
+def test_first_layer_on_the_matrix_cores_equals_the_vector_kernel(ctx):
+    """The detector's 3 -> 64 layer runs on the matrix cores by default; `first_layer_mfma = 0` runs it on the vector
+    ALU.  Both sum the 27 exact products in the same order, so everything downstream is bit-identical - on images large
+    enough that several workgroups share a compute unit (more than 256 tiles of 8 x 64 pixels), uint8 and float input,
+    widths that end in a partial tile."""
+    params = nets.init_east_params(seed=1)
+    ctx.east_load_weights(params)
+    rng = np.random.default_rng(5)
+    cases = [rng.integers(0, 256, (2, 512, 576, 3), dtype=np.uint8), rng.integers(0, 256, (1, 1024, 1024, 3), dtype=np.uint8),
+             rng.normal(0, 1, (1, 544, 480, 3)).astype(np.float32), rng.integers(0, 256, (3, 96, 160, 3), dtype=np.uint8)]
+    try:
+        for img in cases:
+            got = {}
+            for opt in (1, 0, 1):
+                ctx.set_option('first_layer_mfma', opt)
+                maps = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
+                got.setdefault(opt, []).append((ctx.east_activation('pool1'), maps))
+            for pool1, maps in got[1]:
+                np.testing.assert_array_equal(pool1, got[0][0][0])
+                np.testing.assert_array_equal(maps, got[0][0][1])
+    finally:
+        ctx.set_option('first_layer_mfma', 1)
