@@ -318,6 +318,9 @@ int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int 
  * library makes.  Replaces the hierarchical @timer / Timer instrumentation that wraps every stage of
  * the reference (loggers/time_logging.py:27-136, e.g. models/detection/east.py:64,102,153).
  *   ocrhip_profile_enable : enable != 0 starts recording (and drops earlier records), 0 stops
+ *   ocrhip_profile_only   : restricts the recording to launches of one kernel name (as ocrhip_profile_collect reports
+ *                           it); NULL or "" times every launch again.  Two events per launch cost a few microseconds
+ *                           of stream time each: a throughput measurement times only the kernel it wants to price.
  *   ocrhip_profile_collect: synchronises the device, aggregates the records per kernel name, writes
  *                           at most `cap` entries sorted by total time and sets *n to the number of
  *                           distinct kernels; flops / bytes are the ALGORITHMIC work of the launches
@@ -332,6 +335,7 @@ typedef struct {
 } ocrhip_kernel_stat;
 
 int ocrhip_profile_enable(ocrhip_handle h, int enable);
+int ocrhip_profile_only(ocrhip_handle h, const char* name);
 int ocrhip_profile_collect(ocrhip_handle h, ocrhip_kernel_stat* out, int cap, int* n);
 
 #ifdef __cplusplus

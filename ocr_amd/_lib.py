@@ -34,6 +34,7 @@ SIGNATURES = {
     'ocrhip_east_load_weights': (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_int]),
     'ocrhip_set_option': (c_int, [c_void_p, c_char_p, c_int]),
     'ocrhip_dice_coeff': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    'ocrhip_profile_only': (c_int, [c_void_p, c_char_p]),
     'ocrhip_image_resize_norm': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ocrhip_east_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ocrhip_east_get_activation': (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64)]),

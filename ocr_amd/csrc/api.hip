@@ -77,7 +77,7 @@ void Profiler::recycle() {
 }
 
 ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : p(current_profiler()), s(stream), idx(0) {
-    if (!p || !p->enabled) {
+    if (!p || !p->enabled || (!p->only.empty() && p->only != name)) {
         p = nullptr;
         return;
     }
@@ -980,6 +980,13 @@ int ocrhip_profile_enable(ocrhip_handle h, int enable) {
     OCR_HIP_CHECK(hipDeviceSynchronize());
     h->prof.recycle();
     h->prof.enabled = enable != 0;
+    return OCRHIP_OK;
+}
+
+int ocrhip_profile_only(ocrhip_handle h, const char* name) {
+    OCR_HANDLE(h);
+    OCR_HIP_CHECK(hipDeviceSynchronize());
+    h->prof.only = name ? name : "";
     return OCRHIP_OK;
 }
 

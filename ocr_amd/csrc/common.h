@@ -48,6 +48,7 @@ struct ProfRecord {
 };
 struct Profiler {
     bool enabled = false;
+    std::string only;          // when not empty: only launches recorded under this name are timed
     std::vector<ProfRecord> records;
     std::vector<hipEvent_t> pool;
     hipEvent_t get_event();

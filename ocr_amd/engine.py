@@ -91,6 +91,10 @@ class HipContext:
     def profile_enable(self, enable=True):
         check(self.lib.ocrhip_profile_enable(self._h, 1 if enable else 0))
 
+    def profile_only(self, name=None):
+        """Times only the launches recorded under `name` (None: all of them again)."""
+        check(self.lib.ocrhip_profile_only(self._h, name.encode() if name else None))
+
     def profile_collect(self, cap=64):
         """-> list of dict(name, launches, total_ms, flops, bytes) sorted by total time (synchronises)."""
         arr = (_lib.KernelStat * cap)()
