@@ -214,15 +214,28 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const void* __rest
     }
     // input tile: rows oy0 - 1 .. oy0 + 8, columns ox0 - 1 .. ox0 + 64, zero outside the image (the padding of the
     // normalised tensor); consecutive elements of a row are consecutive in memory
-    for (int e = tid; e < IN_FLOATS; e += 256) {
+    // (all loads of the thread first: one memory round trip)
+    constexpr int NLD = (IN_FLOATS + 255) / 256;
+    float ld[NLD];
+    int raw[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int e = tid + 256 * j;
         const int r = e / (IW * 3), rem = e % (IW * 3);
         const int yy = oy0 - 1 + r, xx = ox0 - 1 + rem / 3;
-        float v = 0.0f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        ld[j] = 0.0f;
+        raw[j] = -1;
+        if (e < IN_FLOATS && yy >= 0 && yy < H && xx >= 0 && xx < W) {
             const int64_t idx = (((int64_t)b * H + yy) * W + ox0 - 1) * 3 + rem;
-            v = U8 ? lut[reinterpret_cast<const uint8_t*>(xin)[idx]] : reinterpret_cast<const float*>(xin)[idx];
+            if (U8) raw[j] = reinterpret_cast<const uint8_t*>(xin)[idx];
+            else ld[j] = reinterpret_cast<const float*>(xin)[idx];
         }
-        s_in[e] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int e = tid + 256 * j;
+        if (U8 && raw[j] >= 0) ld[j] = lut[raw[j]];
+        if (e < IN_FLOATS) s_in[e] = ld[j];
     }
     // weights [k = (ky * 3 + kx) * 3 + c][64]: step s uses k = 2 s + lh, the 28th k is zero
     float bw[14][2];
@@ -289,6 +302,86 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const void* __rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// The recogniser's first layer (1 -> 32 channels, 3x3, ReLU, 2x2 max-pool) on the matrix cores.  K = 9 (+ one zero) is five
+// v_mfma_f32_32x32x2_f32 for 32 pre-pool pixels x 32 channels.  The 32 rows of a unit are 8 pooled pixels of one pooled
+// row, row i = 4 g + s being sub-pixel s = 2 dy + dx of pooled pixel g: the four pre-pool results of a pooled pixel
+// then sit in registers 4 q .. 4 q + 3 of ONE lane (accumulator register v of a lane holds row (v & 3) + 8 (v >> 2) +
+// 4 (lane >> 5)), so the pooling is three v_max in registers, and for a fixed q the lanes of a wave hold 2 pixels x 32
+// consecutive channels = 256 contiguous bytes of the NHWC output: plain coalesced stores, no transpose.  A workgroup
+// owns 8 pooled rows x 64 pooled columns of one image: its 18 x 130 input values go through LDS once.  Same products in
+// the same order as conv_first_kernel, max and bias + ReLU in the same order: identical results.
+__global__ __launch_bounds__(256) void conv_first_pool_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, float* __restrict__ y,
+                                                                   int H, int W) {
+    constexpr int PR = 8, PC = 64;                     // pooled rows x columns of the workgroup
+    constexpr int IH = 2 * PR + 2, IW = 2 * PC + 2;    // input rows x columns incl. the border
+    __shared__ float s_in[IH * IW + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, lh = lane >> 5;
+    const int Ho = H / 2, Wo = W / 2;
+    const int xo0 = blockIdx.x * PC, yo0 = blockIdx.y * PR, b = blockIdx.z;
+    const float* img = x + (int64_t)b * H * W;
+
+    // all loads of the thread first (one memory round trip), then the LDS writes
+    constexpr int NLD = (IH * IW + 255) / 256;
+    float ld[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int e = tid + 256 * j;
+        const int r = e / IW, c = e % IW;
+        const int yy = 2 * yo0 - 1 + r, xx = 2 * xo0 - 1 + c;
+        ld[j] = (e < IH * IW && yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(int64_t)yy * W + xx] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j)
+        if (tid + 256 * j < IH * IW) s_in[tid + 256 * j] = ld[j];
+    // weights [k = ky * 3 + kx][32]: step st uses k = 2 st + lh, the 10th k is zero
+    float bw[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int k = 2 * st + lh;
+        bw[st] = (k < 9) ? w[k * 32 + i] : 0.0f;
+    }
+    const float bv = bias[i];
+    // LDS offsets of the lane's five input values relative to (pooled row r, unit column u): row i = 4 g + s of the unit is
+    // pre-pool pixel (2 r + (s >> 1), 16 u + 2 g + (s & 1)); k = (ky, kx) reads input (row + ky - 1, column + kx - 1), and
+    // the LDS image starts at row -1, column -1
+    const int g = i >> 2, sub = i & 3;
+    int aoff[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int k = min(2 * st + lh, 8);
+        aoff[st] = ((sub >> 1) + k / 3) * IW + 2 * g + (sub & 1) + k % 3;
+    }
+    __syncthreads();
+
+    // units of the wave: pooled rows 2 wave, 2 wave + 1, eight units of 8 pooled columns each
+    for (int u = 0; u < 16; ++u) {
+        const int r = wave * 2 + (u >> 3), uc = u & 7;
+        const int yo = yo0 + r, xo = xo0 + uc * 8;
+        if (yo >= Ho || xo >= Wo) continue;               // uniform
+        const float* src = s_in + (2 * r) * IW + 16 * uc;
+        float av[5];
+#pragma unroll
+        for (int st = 0; st < 5; ++st) av[st] = src[aoff[st]];
+        av[4] = lh ? 0.0f : av[4];
+        floatx16_cf acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < 5; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bw[st], acc, 0, 0, 0);
+        float* dst = y + (((int64_t)b * Ho + yo) * Wo + xo) * 32 + i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = fmaxf(fmaxf(acc[4 * q], acc[4 * q + 1]), fmaxf(acc[4 * q + 2], acc[4 * q + 3]));
+            v = fmaxf(v + bv, 0.0f);
+            const int px = 2 * q + lh;                      // pooled pixel of the unit
+            if (xo + px < Wo) dst[px * 32] = v;
+        }
     }
 }
 
@@ -359,8 +452,13 @@ int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y,
             hipLaunchKernelGGL((conv_first_rows_kernel<3, 64, false, 8>), grid, block, 0, s, x, w, bias, y, H, W);
     } else if (L.cin == 1 && L.cout == 32 && pool == 1 && !x_is_u8) {
         OCR_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_first: pooled layer needs even H, W (got %dx%d)", H, W);
-        dim3 grid((W / 2 + 63) / 64, H / 2, B), block(256);
-        hipLaunchKernelGGL((conv_first_kernel<1, 32, true, false>), grid, block, 0, s, x, w, bias, y, H, W);
+        if (first_layer_mfma()) {
+            dim3 grid((W / 2 + 63) / 64, (H / 2 + 7) / 8, B), block(256);
+            hipLaunchKernelGGL(conv_first_pool_mfma_kernel, grid, block, 0, s, reinterpret_cast<const float*>(x), w, bias, y, H, W);
+        } else {
+            dim3 grid((W / 2 + 63) / 64, H / 2, B), block(256);
+            hipLaunchKernelGGL((conv_first_kernel<1, 32, true, false>), grid, block, 0, s, x, w, bias, y, H, W);
+        }
     } else if (L.cin == 1 && L.cout == 32 && pool == 0 && !x_is_u8) {
         dim3 grid((W + 63) / 64, H, B), block(256);
         hipLaunchKernelGGL((conv_first_kernel<1, 32, false, false>), grid, block, 0, s, x, w, bias, y, H, W);

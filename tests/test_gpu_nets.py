@@ -381,5 +381,15 @@ def test_first_layer_on_the_matrix_cores_equals_the_vector_kernel(ctx):
             for pool1, maps in got[1]:
                 np.testing.assert_array_equal(pool1, got[0][0][0])
                 np.testing.assert_array_equal(maps, got[0][0][1])
+        # the recogniser's pooled 1 -> 32 first layer likewise: widths with full and partial tiles of 64 pooled columns
+        cp = nets.init_crnn_params(vocab_size=97, seed=2)
+        ctx.crnn_load_weights(cp)
+        for n, wpad in ((300, 64), (40, 192), (17, 320), (3, 1040)):
+            x = torch.from_numpy(rng.uniform(-1, 1, (n, 64, wpad, 1)).astype(np.float32)).cuda()
+            got = {}
+            for opt in (1, 0):
+                ctx.set_option('first_layer_mfma', opt)
+                got[opt] = ctx.crnn_forward(x, want_logits=True)['logits'].cpu().numpy()
+            np.testing.assert_array_equal(got[1], got[0])
     finally:
         ctx.set_option('first_layer_mfma', 1)
