@@ -150,7 +150,12 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
                 const unsigned fl_l = u_valid ? im.flags[u_l] : 0u;
                 const float area_l = box_area(bu_l);
                 const float w_l = (weighted && u_valid) ? im.wcur[u_l] : 0.f;
-                for (int k = 0; k < cnt; ++k) {
+                // only the boxes of S that reach into the bounds of tile T can overlap one of its boxes (thr > 0)
+                unsigned long long todo = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);
+                if (cull) todo &= __ballot(u_valid && (bu_l.x <= tb.z) && (tb.x <= bu_l.z) && (bu_l.y <= tb.w) && (tb.y <= bu_l.w));
+                while (todo) {
+                    const int k = __builtin_ctzll(todo);
+                    todo &= todo - 1;
                     const float ux1 = bcast(bu_l.x, k), uy1 = bcast(bu_l.y, k);
                     const float ux2 = bcast(bu_l.z, k), uy2 = bcast(bu_l.w, k);
                     const float iw = fmaxf(0.f, fminf(bt.z, ux2) - fmaxf(bt.x, ux1));
