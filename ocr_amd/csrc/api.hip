@@ -47,7 +47,7 @@ static thread_local int g_wino4_split = 1;
 int wino4_split() { return g_wino4_split; }
 void set_wino4_split(int on) { g_wino4_split = on; }
 static thread_local int g_fuse_ctc = 1;
-static thread_local int g_wino4_wave_tiles = 1;
+static thread_local int g_wino4_wave_tiles = 2;
 int wino4_wave_tiles() { return g_wino4_wave_tiles; }
 void set_wino4_wave_tiles(int on) { g_wino4_wave_tiles = on; }
 static thread_local int g_first_layer_mfma = 1;
@@ -295,7 +295,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     if (!h) return OCRHIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.w_wino4.release(); L.w_wino4b.release(); L.w_bf16.release(); L.bias.release(); L.w_gemm.release(); L.bias_gemm.release(); };
+    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.w_wino4.release(); L.w_wino4b.release(); L.w_wino4c.release(); L.w_bf16.release(); L.bias.release(); L.w_gemm.release(); L.bias_gemm.release(); };
     for (auto& L : h->crnn.rconv) free_layer(L);
     for (auto& L : h->east.vgg) free_layer(L);
     for (auto& L : h->east.merge) free_layer(L);
@@ -957,7 +957,7 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "wino4_wave_tiles") == 0) {
-        OCR_REQUIRE(value == 0 || value == 1, "set_option: wino4_wave_tiles is 0 or 1");
+        OCR_REQUIRE(value >= 0 && value <= 2, "set_option: wino4_wave_tiles is 0, 1 or 2");
         h->wino4_wave_tiles = value;
         return OCRHIP_OK;
     }

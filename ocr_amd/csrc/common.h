@@ -110,6 +110,7 @@ struct ConvLayer {
     DevBuf w_bf16;          // bfloat16 slab of the same layer (see conv_bf16.hip), when cin % 16 == 0
     DevBuf w_wino;          // 3x3 layers with >= 64 output channels: Winograd-transformed filters (see conv_wino.hip)
     DevBuf w_wino4;         // the same layers: F(4x4,3x3)-transformed filters (see conv_wino4.hip)
+    DevBuf w_wino4c;        // of those, layers with a multiple of 128 output channels: the layout of its MODE 4
     DevBuf w_wino4b;        // layers with < 256 input channels: the same filters in the layout of that kernel's MODE 3
     DevBuf bias;            // cout_pad floats, folded
     DevBuf w_gemm, bias_gemm;   // 1x1 and 2x2 layers: slabs and bias for the 256 x 128 flat GEMM (see gemm_f32.hip)
@@ -169,7 +170,7 @@ struct ocrhip_ctx {
     int lstm_persistent = 1;       // recurrence of a BiLSTM layer in one persistent launch (1) or one launch per step (0)
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     int first_layer_mfma = 1;      // the detector's 3 -> 64 first layer on the matrix cores (1) or on the vector ALU (0); identical results
-    int wino4_wave_tiles = 1;      // fused F(4x4,3x3) layers: waves own whole (block, channel) tiles of 8 x 32 outputs, inverse transform in registers, two workgroups per CU (1), or the 3x3-component split with staged partial sums on 16 x 32 tiles (0)
+    int wino4_wave_tiles = 2;      // fused F(4x4,3x3) layers: waves own whole (block, channel) tiles of 8 x 32 outputs, inverse transform in registers: workgroups of 4 waves x 16 channels, two per CU (1); the same, and workgroups of 8 waves x 16 channels where the layer has a multiple of 128 output channels (2); or the 3x3-component split with staged partial sums on 16 x 32 tiles (0)
     int wino4_split = 1;           // F(4x4,3x3) layers with >= 512 input channels: transform once into `wino_ws`, multiply from it (1) or fused (0)
     ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
     int fuse_ctc = 1;              // tokens without a logits request: class layer reduced to per-block maxima in its epilogue (1) or logits written and re-read (0)

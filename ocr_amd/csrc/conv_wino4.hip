@@ -57,6 +57,10 @@ constexpr int kLdsBytes = 4 * (kLoopFloats > kStageFloats ? kLoopFloats : kStage
 constexpr int kLoopFloats3 = 2 * (36 * 16 * kCK) + 2 * (kRawW * 10 * kRS + 4);
 constexpr int kStageFloats3 = 8 * 32 * kOS;
 constexpr int kLdsBytes3 = 4 * (kLoopFloats3 > kStageFloats3 ? kLoopFloats3 : kStageFloats3);
+// MODE 4 (half tiles, 128 output channels, chunks of 16 input channels): twice the loop buffers; 128 + 4 floats per staged pixel
+constexpr int kLoopFloats4 = 2 * kLoopFloats3;
+constexpr int kStageFloats4 = 8 * 32 * (128 + 4);
+constexpr int kLdsBytes4 = 4 * (kLoopFloats4 > kStageFloats4 ? kLoopFloats4 : kStageFloats4);
 constexpr int kWChunkFloats = 36 * 2 * 64 * 4;  // transformed filters of one chunk of one 64-channel block
 constexpr int kSplitMinCin = 512;               // layers at least this deep run as transform kernel + multiply kernel
 
@@ -128,12 +132,17 @@ __device__ __forceinline__ void inverse_part(const float (&M)[3][3], float (&Y)[
 template <int POOL, int MODE>
 __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv_wino4_f32_kernel(const Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // U[2] then raw[2]: chunk j lives in buffer j & 1
-    constexpr bool W3 = (MODE == 3);                       // the variant whose waves own whole (block, channel) tiles
-    constexpr int NT = W3 ? 256 : 512;                     // threads
+    constexpr bool W4 = (MODE == 4);                       // wave tiles, 8 waves x 16 = 128 output channels from one transformed tile
+    constexpr bool W3 = (MODE == 3 || W4);                 // the variants whose waves own whole (block, channel) tiles
+    constexpr int NT = (MODE == 3) ? 256 : 512;            // threads
     constexpr int NBLK = W3 ? 16 : 32;                     // 4x4 blocks of a workgroup's tile
     constexpr int TH = NBLK / 2;                           // output rows of the tile
     constexpr int UC = NBLK * kCK, UF = 36 * UC;           // floats per component of U, per U
     constexpr int RH = W3 ? 10 : kRawH, RPX = kRawW * RH, RF = RPX * kRS, RB = RF + 4;      // raw tile
+    constexpr int NSUB = W4 ? 2 : 1;                       // 8-channel sub-chunks of a K chunk: each has its own U and raw tile
+    constexpr int CKK = kCK * NSUB;                        // input channels per chunk
+    constexpr int NCH = W4 ? 128 : 64;                     // output channels of a workgroup
+    constexpr int WCF = W4 ? 4 * kWChunkFloats : kWChunkFloats;      // floats of a chunk of the filter slab
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -149,23 +158,18 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
     const int b = tile_all / a.tiles_per_image;
     const int tile = tile_all % a.tiles_per_image;
     const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * 32;      // pair mode: b counts pairs, y0 = 0
-    const int nK = a.cin / kCK;
+    const int nK = a.cin / CKK;
     const int pair = a.pair;
 
     // bias now: a load still in flight in the epilogue would stall its guarded stores
-    const int c4 = tid & 15;
-    const int co0 = nb * 64 + c4 * 4;
+    const int c4 = tid & (NCH / 4 - 1);
+    const int co0 = nb * NCH + c4 * 4;
     floatx4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE != 1) bias4 = *reinterpret_cast<const floatx4*>(a.bias + co0);          // bias is padded to cout_pad
 
     floatx16 acc[W3 ? 1 : 9];
     floatx4 acc3[W3 ? 36 : 1];                  // MODE 3: component f of blocks 4 (lane / 16) + v, channel 16 cq + lane % 16
-    if constexpr (W3) {
-#pragma unroll
-        for (int f = 0; f < 36; ++f)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc3[f][v] = 0.0f;
-    } else {
+    if constexpr (!W3) {          // MODE 3 / 4: the first chunk's MFMAs take zero as their addend instead
 #pragma unroll
         for (int f = 0; f < 9; ++f)
 #pragma unroll
@@ -175,8 +179,8 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
     // Global loads go through buffer descriptors: a per-lane byte offset that never changes, the chunk as a scalar
     // offset, and the range check, which returns zeros beyond the buffer: the zero padding around the image costs no
     // instruction (lanes outside the image carry the offset 2^31).
-    const float* wslab = a.w + (int64_t)nb * nK * kWChunkFloats;
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wslab, 0, nK * kWChunkFloats * 4, 0x00020000);
+    const float* wslab = a.w + (int64_t)nb * nK * WCF;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wslab, 0, nK * WCF * 4, 0x00020000);
     const int w_off = ((((3 * gr) * 6 + 3 * gc) * 2 + ch) * 64 + lane) * 16;
     auto load_w = [&](int kc, int f) {          // fragment of component (3 gr + f / 3, 3 gc + f % 3) of chunk kc
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off, kc * (kWChunkFloats * 4) + ((f / 3) * 6 + f % 3) * 2048, 0));
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
 
     // raw tile: 18 x 34 pixels (rows y0 - 1 .. y0 + 16) x 2 channel quads over the threads.  Pair mode: 20 rows = for each
     // of the two images its 8 rows between two rows of zeros, so that no block reads its neighbour image as padding.
-    constexpr int NRAW = (RPX * 2 + NT - 1) / NT;
+    constexpr int NRAW = (RPX * 2 * NSUB + NT - 1) / NT;
     const int64_t img_floats = (int64_t)a.H * a.W * a.cin;
     const int n_img = pair ? min(2, a.B - 2 * b) : 1;          // a missing second image reads as zeros (range check)
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)b * (pair ? 2 : 1) * img_floats), 0,
@@ -193,19 +197,23 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
     int raw_src[NRAW], raw_dst[NRAW];
 #pragma unroll
     for (int i = 0; i < NRAW; ++i) {
-        const int f = tid + i * NT;
+        // MODE 4: 2 x 680 elements over 512 threads as (sub-chunk 0, first 512), (sub-chunk 1, first 512), (sub-chunk
+        // tid / 256, the remaining 168): the second differs from the first by constants in both addresses
+        const int sub = W4 ? (i == 2 ? (tid >> 8) : i) : 0;
+        const int f = W4 ? (i == 2 ? NT + (tid & 255) : tid) : tid + i * NT;
+        const int fa = f < RPX * 2 ? sub * (RPX * 2) + f : RPX * 2 * NSUB;
         const int px = f >> 1, q = f & 1;
         const int rr = px / kRawW, gx = x0 - 1 + px % kRawW;
         const int img = (pair && rr >= 10) ? 1 : 0;
         const int gy = pair ? rr - 10 * img - 1 : y0 - 1 + rr;
-        const bool ok = f < RPX * 2 && (pair || W3 || rr < 18) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        raw_src[i] = ok ? ((((img * a.H + gy) * a.W + gx) * a.cin + q * 4) * 4) : (int)0x80000000;
-        raw_dst[i] = (f < RPX * 2) ? (px * kRS + q * 4) : RF;
+        const bool ok = fa < RPX * 2 * NSUB && (pair || W3 || rr < 18) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        raw_src[i] = ok ? ((((img * a.H + gy) * a.W + gx) * a.cin + sub * kCK + q * 4) * 4) : (int)0x80000000;
+        raw_dst[i] = (fa < RPX * 2 * NSUB) ? (sub * RB + px * kRS + q * 4) : RF;
     }
     auto load_raw = [&](int kc) {
 #pragma unroll
         for (int i = 0; i < NRAW; ++i)
-            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, raw_src[i], kc * (kCK * 4), 0));
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, raw_src[i], kc * (CKK * 4), 0));
     };
     auto store_raw = [&](int rbase) {
 #pragma unroll
@@ -225,8 +233,13 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
     // pair task and one single task.  The roles are uniform in a wave: the code is specialised per role.
     const int t_p = lane & 3, t_bx = (lane >> 2) & 7, t_bylo = lane >> 5;
     auto transform = [&](int rbase, int ubase) {
-        // role 0: rows 1, 2; 1: rows 3, 4; 2: row 0; 3: row 5.  MODE 3: one half, the four roles over the four waves
-        const int half = W3 ? 0 : (wave & 1), role = W3 ? wave : (wave >> 1);
+        // role 0: rows 1, 2; 1: rows 3, 4; 2: row 0; 3: row 5.  MODE 3: one half, the four roles over the four waves;
+        // MODE 4: waves 0..3 transform the first 8 channels of the chunk, waves 4..7 the other 8
+        const int half = W3 ? 0 : (wave & 1), role = W3 ? (wave & 3) : (wave >> 1);
+        if constexpr (W4) {
+            rbase += (wave >> 2) * RB;
+            ubase += (wave >> 2) * UF;
+        }
         const int by = half * 2 + t_bylo;
         const int m = by * 8 + t_bx;
         const float* src = &lds[rbase + ((by * 4 + (pair ? 2 * (by >> 1) : 0)) * kRawW + t_bx * 4) * kRS + t_p * 2];
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
         for (int jj = 0; jj < 3; ++jj) af[jj] = *reinterpret_cast<const float4*>(&lds[ubase + u_src + (g * 6 + jj) * kUC]);
     };
 
-    constexpr int kR0 = 2 * UF, kR1 = 2 * UF + RB;
+    constexpr int kR0 = 2 * NSUB * UF, kR1 = kR0 + NSUB * RB;
     if constexpr (MODE == 1) {
         // transform only: chunks [nb * chunks_per_group, ...) of this tile -> v
         const int k_lo = nb * a.chunks_per_group, k_hi = min(nK, k_lo + a.chunks_per_group);
@@ -403,19 +416,21 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
         const int l16 = lane & 15, q = lane >> 4;
         // Filter slab of MODE 3: [chunk][f2 = 0..17][cq][lane][4 floats] = components 2 f2, 2 f2 + 1 x input channels
         // 2 q, 2 q + 1 of the chunk, for output channel 16 cq + lane % 16: one 16-byte load feeds four MFMAs.
+        // MODE 4: [chunk of 16][sub-chunk][f2][cq = 0..7][lane][4 floats]: step = 18 sub + f2
         const int w3_off = (cq * 64 + lane) * 16;
-        auto load_w3 = [&](int kc, int f2) {
-            return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w3_off, kc * (kWChunkFloats * 4) + f2 * 4096, 0));
+        auto load_w3 = [&](int kc, int step) {
+            return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w3_off, kc * (WCF * 4) + step * (NCH * 64), 0));
         };
-        float4 bw3[9];                                    // fragment ring: step s (two components) sits in slot s % 9, reloaded 9 steps ahead
+        constexpr int RING = W4 ? 6 : 9;                  // 18 steps per sub-chunk are a multiple of both
+        float4 bw3[RING];                                 // fragment ring: step s (two components) sits in slot s % RING, reloaded RING steps ahead
         {
             float4 rb[NRAW];                             // raw tiles 0 and 1 requested together: one memory round trip
             load_raw(0);
 #pragma unroll
             for (int i = 0; i < NRAW; ++i)
-                rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, raw_src[i], kCK * 4, 0));
+                rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, raw_src[i], CKK * 4, 0));
 #pragma unroll
-            for (int f = 0; f < 9; ++f) bw3[f] = load_w3(0, f);
+            for (int f = 0; f < RING; ++f) bw3[f] = load_w3(0, f);
             store_raw(kR0);
 #pragma unroll
             for (int i = 0; i < NRAW; ++i) {
@@ -431,15 +446,24 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
         // operands of a lane within a component pair of U: block lane % 16, channels 2 q and 2 q + 1 of both
         // components (k of the two MFMAs that consume the chunk's 8 channels: k = lane / 16, channel = 2 k + step)
         const int u3 = l16 * (2 * kCK) + 4 * q;
-        auto chunk3 = [&](int kc, auto parity) {
+        auto chunk3 = [&](int kc, auto parity, auto first_chunk) {
             constexpr int P = decltype(parity)::value;
-            constexpr int ucur = P * UF, unxt = (1 - P) * UF;
-            constexpr int rnxt = kR0 + (1 - P) * RB, rfill = kR0 + P * RB;
+            constexpr bool FIRST = decltype(first_chunk)::value;       // nothing accumulated yet: 144 register clears saved
+            const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            constexpr int ucur = P * NSUB * UF, unxt = (1 - P) * NSUB * UF;
+            constexpr int rnxt = kR0 + (1 - P) * NSUB * RB, rfill = kR0 + P * NSUB * RB;
+            constexpr int NG = 9 * NSUB;                // groups of 4 components; the sub-chunks' U lie back to back
             const int kn = min(kc + 1, nK - 1);
-            if (kc + 1 < nK) {                          // uniform
-                transform(rnxt, unxt);
+            // MODE 4: the two waves of a SIMD (w and w + 4) belong to one workgroup and meet at every barrier; the second
+            // one transforms AFTER its multiplications, so that one of them has MFMAs to issue while the other transforms
+            const bool late = W4 && wave >= 4;          // uniform
+            // The loads of the raw tile go out BEFORE the transform: loads return in order, so the first filter fragment
+            // requested after them waits for them too, and it is needed RING steps into the multiplications.
+            if (kc + 1 < nK && !late) {                 // uniform
                 store_raw(rfill);
                 load_raw(min(kc + 3, nK - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                transform(rnxt, unxt);
             }
             __builtin_amdgcn_sched_barrier(0);
             const float* ub = &lds[ucur + u3];
@@ -447,38 +471,50 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
 #pragma unroll
             for (int c = 0; c < 2; ++c) a4[0][c] = *reinterpret_cast<const float4*>(ub + c * (2 * UC));
 #pragma unroll
-            for (int g = 0; g < 9; ++g) {
-                if (g + 1 < 9) {
+            for (int gg = 0; gg < NG; ++gg) {
+                const int g = gg % 9;
+                if (gg + 1 < NG) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) a4[(g + 1) & 1][c] = *reinterpret_cast<const float4*>(ub + (2 * (g + 1) + c) * (2 * UC));
+                    for (int c = 0; c < 2; ++c) a4[(gg + 1) & 1][c] = *reinterpret_cast<const float4*>(ub + (2 * (gg + 1) + c) * (2 * UC));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const floatx2 av[4] = {floatx2{a4[g & 1][0].x, a4[g & 1][0].y}, floatx2{a4[g & 1][0].z, a4[g & 1][0].w},
-                                       floatx2{a4[g & 1][1].x, a4[g & 1][1].y}, floatx2{a4[g & 1][1].z, a4[g & 1][1].w}};
-                const float4 b0 = bw3[(2 * g) % 9], b1 = bw3[(2 * g + 1) % 9];
+                const floatx2 av[4] = {floatx2{a4[gg & 1][0].x, a4[gg & 1][0].y}, floatx2{a4[gg & 1][0].z, a4[gg & 1][0].w},
+                                       floatx2{a4[gg & 1][1].x, a4[gg & 1][1].y}, floatx2{a4[gg & 1][1].z, a4[gg & 1][1].w}};
+                const float4 b0 = bw3[(2 * g) % RING], b1 = bw3[(2 * g + 1) % RING];
                 // the two MFMAs of a component (its 8 channels) sit four instructions apart
-                acc3[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].x, b0.x, acc3[4 * g + 0], 0, 0, 0);
-                acc3[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].x, b0.z, acc3[4 * g + 1], 0, 0, 0);
-                acc3[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2].x, b1.x, acc3[4 * g + 2], 0, 0, 0);
-                acc3[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3].x, b1.z, acc3[4 * g + 3], 0, 0, 0);
+                const bool fresh = FIRST && gg < 9;
+                acc3[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].x, b0.x, fresh ? zero4 : acc3[4 * g + 0], 0, 0, 0);
+                acc3[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].x, b0.z, fresh ? zero4 : acc3[4 * g + 1], 0, 0, 0);
+                acc3[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2].x, b1.x, fresh ? zero4 : acc3[4 * g + 2], 0, 0, 0);
+                acc3[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3].x, b1.z, fresh ? zero4 : acc3[4 * g + 3], 0, 0, 0);
                 acc3[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].y, b0.y, acc3[4 * g + 0], 0, 0, 0);
                 acc3[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].y, b0.w, acc3[4 * g + 1], 0, 0, 0);
                 acc3[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2].y, b1.y, acc3[4 * g + 2], 0, 0, 0);
                 acc3[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3].y, b1.w, acc3[4 * g + 3], 0, 0, 0);
-                // the two slots just used: refilled with the fragments nine steps on (this chunk's second half, or the
+                // the two slots just used: refilled with the fragments RING steps on (this chunk's second half, or the
                 // next chunk's first half)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    const int st = 2 * g + d + 9;
-                    bw3[(2 * g + d) % 9] = (st < 18) ? load_w3(kc, st) : load_w3(kn, st - 18);
+                    const int st = 2 * gg + d + RING;
+                    bw3[(2 * g + d) % RING] = (st < 2 * NG) ? load_w3(kc, st) : load_w3(kn, st - 2 * NG);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (W4) {
+                if (kc + 1 < nK && late) {
+                    store_raw(rfill);
+                    load_raw(min(kc + 3, nK - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    transform(rnxt, unxt);
+                }
+            }
             __syncthreads();
         };
-        for (int kc = 0; kc < nK; kc += 2) {          // nK is even
-            chunk3(kc, std::integral_constant<int, 0>{});
-            chunk3(kc + 1, std::integral_constant<int, 1>{});
+        chunk3(0, std::integral_constant<int, 0>{}, std::true_type{});
+        chunk3(1, std::integral_constant<int, 1>{}, std::false_type{});
+        for (int kc = 2; kc < nK; kc += 2) {          // nK is even
+            chunk3(kc, std::integral_constant<int, 0>{}, std::false_type{});
+            chunk3(kc + 1, std::integral_constant<int, 1>{}, std::false_type{});
         }
 
         // ---- epilogue: Y = A^T M A per (block, channel) in registers, max-pool in registers, the (pooled) tile staged in
@@ -486,8 +522,11 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
         // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].
         constexpr int PW = (POOL == 1) ? 2 : 4, PH = (POOL == 0) ? 4 : 2;      // outputs a block keeps after pooling
         constexpr int kTW = 8 * PW, kTH = (NBLK / 8) * PH;                     // the tile after pooling
-        auto at4 = [](float m0, float m1, float m2, float m3, float m4, float m5, float (&o)[4]) {
-            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+        constexpr int OS = NCH + 4;                                            // floats per staged pixel
+        // two of a lane's four blocks at a time (registers v and v + 1 of every accumulator: neighbours in a block row),
+        // so that the additions are packed ones
+        auto at4 = [](floatx2 m0, floatx2 m1, floatx2 m2, floatx2 m3, floatx2 m4, floatx2 m5, floatx2 (&o)[4]) {
+            const floatx2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
             o[0] = (m0 + s1) + s2;
             o[1] = d1 + 2.0f * d2;
             o[2] = s1 + 4.0f * s2;
@@ -495,34 +534,37 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
         };
         const int ch3 = cq * 16 + l16;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int m = 4 * q + v, by = m >> 3, bx = m & 7;
-            float Wt[6][4];
+        for (int vp = 0; vp < 2; ++vp) {
+            auto M = [&](int f) { return floatx2{acc3[f][2 * vp], acc3[f][2 * vp + 1]}; };
+            floatx2 Wt[6][4];
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
-                at4(acc3[i * 6 + 0][v], acc3[i * 6 + 1][v], acc3[i * 6 + 2][v], acc3[i * 6 + 3][v], acc3[i * 6 + 4][v], acc3[i * 6 + 5][v], Wt[i]);
-            float Y[4][4];
+            for (int i = 0; i < 6; ++i) at4(M(i * 6 + 0), M(i * 6 + 1), M(i * 6 + 2), M(i * 6 + 3), M(i * 6 + 4), M(i * 6 + 5), Wt[i]);
+            floatx2 Y[4][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float col[4];
+                floatx2 col[4];
                 at4(Wt[0][c], Wt[1][c], Wt[2][c], Wt[3][c], Wt[4][c], Wt[5][c], col);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Y[r][c] = col[r];
             }
-            // the four lane groups of a wave (q) write pixels a multiple of 64 floats apart: each rotates its 64 channels
-            // by a different quarter so that they use different LDS banks
-            const int pos = (ch3 + 16 * ((bx >> 2) & 1) + 32 * (by & 1)) & 63;
-            float* O = &lds[((by * PH) * kTW + bx * PW) * kOS + pos];
 #pragma unroll
-            for (int r = 0; r < PH; ++r)
+            for (int e = 0; e < 2; ++e) {
+                const int m = 4 * q + 2 * vp + e, by = m >> 3, bx = m & 7;
+                // the four lane groups of a wave (q) write pixels a multiple of 64 floats apart: each rotates its channels
+                // by a different quarter of 64 so that they use different LDS banks
+                const int pos = (ch3 + 16 * ((bx >> 2) & 1) + 32 * (by & 1)) & (NCH - 1);
+                float* O = &lds[((by * PH) * kTW + bx * PW) * OS + pos];
 #pragma unroll
-                for (int c = 0; c < PW; ++c) {
-                    float o;
-                    if (POOL == 0) o = Y[r][c];
-                    else if (POOL == 1) o = fmaxf(fmaxf(Y[2 * r][2 * c], Y[2 * r][2 * c + 1]), fmaxf(Y[2 * r + 1][2 * c], Y[2 * r + 1][2 * c + 1]));
-                    else o = fmaxf(Y[2 * r][c], Y[2 * r + 1][c]);
-                    O[(r * kTW + c) * kOS] = o;
-                }
+                for (int r = 0; r < PH; ++r)
+#pragma unroll
+                    for (int c = 0; c < PW; ++c) {
+                        float o;
+                        if (POOL == 0) o = Y[r][c][e];
+                        else if (POOL == 1) o = fmaxf(fmaxf(Y[2 * r][2 * c][e], Y[2 * r][2 * c + 1][e]), fmaxf(Y[2 * r + 1][2 * c][e], Y[2 * r + 1][2 * c + 1][e]));
+                        else o = fmaxf(Y[2 * r][c][e], Y[2 * r + 1][c][e]);
+                        O[(r * kTW + c) * OS] = o;
+                    }
+            }
         }
         __syncthreads();
         const int Ho3 = (POOL == 0) ? a.H : a.H / 2, Wo3 = (POOL == 1) ? a.W / 2 : a.W;
@@ -532,11 +574,11 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
             // iteration): the lane's byte offset is ONE register for the whole pass, the step goes into the scalar offset
             // of a buffer store, and pixels or channels outside the map get the out-of-range offset 2^31 instead of a
             // branch (the range check looks at the vector offset only).  No 64-bit index arithmetic per store.
-            constexpr int PXI = NT / 16;                                          // pixels per iteration
+            constexpr int PXI = NT / (NCH / 4);                                   // pixels per iteration
             constexpr int NIT = kTW * kTH / PXI;
-            const int lp = tid >> 4, ly = lp / kTW, lx = lp % kTW;
+            const int lp = tid / (NCH / 4), ly = lp / kTW, lx = lp % kTW;
             const int Y0 = (POOL == 0) ? y0 : (y0 >> 1);
-            const int64_t first = (((int64_t)b * Ho3 + Y0) * Wo3 + ox0) * a.cout + nb * 64;      // the tile's first pixel, the block's first channel
+            const int64_t first = (((int64_t)b * Ho3 + Y0) * Wo3 + ox0) * a.cout + nb * NCH;     // the tile's first pixel, the block's first channel
             const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + first), 0, 0x7fffffff, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((POOL == 0 && a.res) ? a.res + first : a.y), 0, (POOL == 0 && a.res) ? 0x7fffffff : 0, 0x00020000);
@@ -552,7 +594,7 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
                 const int voff = ok ? lane_off : (int)0x80000000;
                 const int soff = py_it * row_bytes + px_it * pix_bytes;
                 const int rot = 16 * ((bx >> 2) & 1) + 32 * (by & 1);
-                floatx4 val = *reinterpret_cast<const floatx4*>(&lds[(lp + it * PXI) * kOS + ((c4 * 4 + rot) & 63)]) + bias4;
+                floatx4 val = *reinterpret_cast<const floatx4*>(&lds[(lp + it * PXI) * OS + ((c4 * 4 + rot) & (NCH - 1))]) + bias4;
                 if (POOL == 0 && a.res) val += __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff, soff, 0));
                 if (a.relu) {
                     val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
@@ -563,14 +605,14 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
         }
         // a channel count that is not a multiple of 4: element by element
 #pragma unroll 4
-        for (int it = 0; it < kTW * kTH / (NT / 16); ++it) {
-            const int px = (tid >> 4) + it * (NT / 16);
+        for (int it = 0; it < kTW * kTH / (NT / (NCH / 4)); ++it) {
+            const int px = tid / (NCH / 4) + it * (NT / (NCH / 4));
             const int py = px / kTW, pxx = px % kTW;
             const int by = py / PH, bx = pxx / PW;
             const int yy = ((POOL == 0) ? y0 : (y0 >> 1)) + py, xx = ox0 + pxx;
             if (yy >= Ho3 || xx >= Wo3) continue;
             const int rot = 16 * ((bx >> 2) & 1) + 32 * (by & 1);
-            const floatx4 val = *reinterpret_cast<const floatx4*>(&lds[px * kOS + ((c4 * 4 + rot) & 63)]) + bias4;
+            const floatx4 val = *reinterpret_cast<const floatx4*>(&lds[px * OS + ((c4 * 4 + rot) & (NCH - 1))]) + bias4;
             const int64_t idx = (((int64_t)b * Ho3 + yy) * Wo3 + xx) * a.cout + co0;
             const float e[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
@@ -724,6 +766,25 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
             }
         OCR_TRY(L.w_wino4b.reserve(w3.size() * sizeof(float)));
         OCR_HIP_CHECK(hipMemcpy(L.w_wino4b.ptr, w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (cout % 128 == 0 && cin % 32 == 0) {          // an even number of 16-channel chunks
+            // and in the layout of MODE 4 (workgroups of 128 output channels, chunks of 16 input channels):
+            // [n block of 128][k chunk of 16][sub-chunk][f2][cq = 0..7][lane = 16 q + j][t = 2 (f % 2) + step]:
+            // output channel 128 nblock + 16 cq + j, input channel 16 kchunk + 8 sub + 2 q + step
+            std::vector<float> w4(w3.size(), 0.0f);
+            const int nK16 = cin / 16;
+            for (int o = 0; o < cout; ++o)
+                for (int c = 0; c < cin; ++c) {
+                    const int cq3 = (o % 64) / 16, j = o % 16, q = (c % kCK) / 2, step = c % 2;
+                    const int nb4 = o / 128, cq4 = (o % 128) / 16, kc4 = c / 16, sub = (c % 16) / 8;
+                    for (int f = 0; f < 36; ++f) {
+                        const size_t src = (((((size_t)((o / 64) * nK + c / kCK) * 18 + f / 2) * 4 + cq3) * 64 + (16 * q + j)) * 4) + 2 * (f % 2) + step;
+                        const size_t dst = ((((((size_t)(nb4 * nK16 + kc4) * 2 + sub) * 18 + f / 2) * 8 + cq4) * 64 + (16 * q + j)) * 4) + 2 * (f % 2) + step;
+                        w4[dst] = w3[src];
+                    }
+                }
+            OCR_TRY(L.w_wino4c.reserve(w4.size() * sizeof(float)));
+            OCR_HIP_CHECK(hipMemcpy(L.w_wino4c.ptr, w4.data(), w4.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     return OCRHIP_OK;
 }
@@ -762,11 +823,11 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     OCR_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lds_opt_in_lock(lds_opt_in_mutex);
     bool& lds_opt_in = lds_opt_in_dev[dev & 63];
-#define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2) X(0, 3) X(1, 3) X(2, 3)
+#define OCR_W4_FOR_ALL(X) X(0, 0) X(1, 0) X(2, 0) X(0, 1) X(0, 2) X(1, 2) X(2, 2) X(0, 3) X(1, 3) X(2, 3) X(0, 4) X(1, 4) X(2, 4)
     if (!lds_opt_in) {
 #define OCR_W4_OPT_IN(P, M)                                                                                               \
     OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_f32_kernel<P, M>),                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, M == 3 ? kLdsBytes3 : kLdsBytes));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, M == 3 ? kLdsBytes3 : (M == 4 ? kLdsBytes4 : kLdsBytes)));
         OCR_W4_FOR_ALL(OCR_W4_OPT_IN)
 #undef OCR_W4_OPT_IN
         lds_opt_in = true;
@@ -785,6 +846,13 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
         a.w = L.w_wino4b.as<float>();
         a.pair = 0;
         a.tiles_per_image = a.tiles_x * ((H + 7) / 8);
+        // layers with a multiple of 128 output channels: one workgroup of 8 waves per tile and 128 channels, so that
+        // the data transform of a tile is shared by twice as many multiplications
+        if (L.w_wino4c.ptr && wino4_wave_tiles() >= 2) {
+            mode = 4;
+            a.w = L.w_wino4c.as<float>();
+            a.n_blocks_n = L.cout / 128;
+        }
         wgs_launch = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
         OCR_REQUIRE(wgs_launch < (1ll << 31), "conv_wino4: too many workgroups");
     }
@@ -804,15 +872,15 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     char pname[64];
     static const bool per_layer = getenv("OCRHIP_PROFILE_LAYERS") != nullptr;      // development aid: one profile line per layer shape
     if (per_layer)
-        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<p%d,c%d-%d,h%d>", mode == 2 ? "_mul" : (mode == 3 ? "_h" : ""), pool, L.cin, L.cout, H);
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<p%d,c%d-%d,h%d>", mode == 2 ? "_mul" : (mode >= 3 ? "_h" : ""), pool, L.cin, L.cout, H);
     else
-        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<n64,pool%d,tile%dx32>", mode == 2 ? "_mul" : (mode == 3 ? "_h" : ""), pool, mode == 3 ? 8 : 16);
+        std::snprintf(pname, sizeof(pname), "conv_wino4%s_f32<n%d,pool%d,tile%dx32>", mode == 2 ? "_mul" : (mode >= 3 ? "_h" : ""), mode == 4 ? 128 : 64, pool, mode >= 3 ? 8 : 16);
     ProfScope prof(pname, 2.0 * 9 * L.cin * L.cout * out_px,
                    4.0 * ((mode == 2 ? 0.0 : out_px * L.cin) + out_elems * (residual ? 2.0 : 1.0) + 9.0 * L.cin * L.cout) + (mode == 2 ? (double)v_bytes : 0.0), s);
 #define OCR_W4_LAUNCH(P, M)                                                                                               \
     if (pool == P && mode == M && M != 1)                                                                                 \
         hipLaunchKernelGGL((conv_wino4_f32_kernel<P, M>), dim3((unsigned)wgs_launch), dim3(M == 3 ? 256 : 512),           \
-                           M == 3 ? kLdsBytes3 : kLdsBytes, s, a);
+                           M == 3 ? kLdsBytes3 : (M == 4 ? kLdsBytes4 : kLdsBytes), s, a);
     OCR_W4_FOR_ALL(OCR_W4_LAUNCH)
 #undef OCR_W4_LAUNCH
 #undef OCR_W4_FOR_ALL

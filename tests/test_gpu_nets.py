@@ -267,11 +267,18 @@ def test_direct_3x3_path_matches_oracle_too(ctx, shape):
         ctx.set_option('wino4_wave_tiles', 0)
         parts = (ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy(),
                  ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True)['logits'].cpu().numpy())
+        # whole tiles per wave, but every layer in workgroups of 64 output channels (the default gives the layers with a
+        # multiple of 128 output channels workgroups of 128)
+        ctx.set_option('wino4_wave_tiles', 1)
+        narrow = (ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy(),
+                  ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True)['logits'].cpu().numpy())
     finally:
         ctx.set_option('conv3x3_winograd', 2)
         ctx.set_option('wino4_split', 1)
-        ctx.set_option('wino4_wave_tiles', 1)
+        ctx.set_option('wino4_wave_tiles', 2)
     np.testing.assert_array_equal(fused, maps[2])     # same products in the same order
+    np.testing.assert_array_equal(narrow[0], maps[2])
+    np.testing.assert_array_equal(narrow[1], got)
     _close(parts[0], ref, rtol=1e-4, atol=1e-5)                  # another order of the inverse transform's additions
     _close(parts[1], cref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(cref).max())))
     assert not np.array_equal(parts[0], maps[2])
