@@ -82,12 +82,19 @@ int ocrhip_destroy(ocrhip_handle h);
  *   input tiles once into a workspace, then multiply from it); 0 keeps them fused (every 64-channel workgroup transforms
  *   its tile itself).  Same arithmetic, identical results.
  *   "wino4_wave_tiles": how the fused F(4x4,3x3) launches (fewer than 512 input channels, or all with wino4_split = 0)
- *   divide a tile between the waves.  1 (default): tiles of 8 x 32 outputs, two workgroups of 4 waves per compute unit,
- *   every wave owns whole (block, channel) tiles (16x16x4 matrix instructions, all 36 Winograd components in one lane),
- *   so the inverse transform and the max-pool run in registers and a tile passes one barrier on its way out.  0: tiles
- *   of 16 x 32, one workgroup of 8 waves, waves own 3x3 of the components and sum their partial outputs through LDS.
- *   Same arithmetic up to the order of the inverse transform's additions (both within the 1e-4 tolerance of the parity
- *   tests).
+ *   divide a tile between the waves.  1: tiles of 8 x 32 outputs, two workgroups of 4 waves x 16 channels per compute
+ *   unit, every wave owns whole (block, channel) tiles (16x16x4 matrix instructions, all 36 Winograd components in one
+ *   lane), so the inverse transform and the max-pool run in registers and a tile passes one barrier on its way out.
+ *   2 (default): the same, and layers with a multiple of 128 output channels (and of 32 input channels) run one
+ *   workgroup of 8 waves x 16 channels per tile, so that a tile is transformed once per 128 output channels; results
+ *   identical to 1.  0: tiles of 16 x 32, one workgroup of 8 waves, waves own 3x3 of the components and sum their
+ *   partial outputs through LDS.  Same arithmetic up to the order of the inverse transform's additions (all within
+ *   the 1e-4 tolerance of the parity tests).
+ *   "wino4_side_by_side": 1 (default): a fused F(4x4,3x3) launch over a batch of images whose width is not a multiple
+ *   of the 32-column tile (the recogniser's crops) tiles the batch as one wide image, the images one zero column apart
+ *   (two under 2x2 pooling), so the tiles are full.  An output then shares Winograd patches with its neighbour image:
+ *   results equal the image-by-image launch (0) to the algorithm's rounding error (~1e-5 of the output scale), not bit
+ *   for bit, and depend on which images share a launch to that extent.
  *   "first_layer_mfma": 1 (default) runs the detector's first convolution (3 -> 64 channels) on the matrix cores, 0 on
  *   the vector ALU; both sum the 27 products of an output in the same order: identical results.
  *   "flat_gemm": 1 (default) runs the Dense layers, the LSTM input projections and the 2x2 convolutions as a flat

@@ -46,6 +46,9 @@ void set_current_workspace(DevBuf* ws) { g_workspace = ws; }
 static thread_local int g_wino4_split = 1;
 int wino4_split() { return g_wino4_split; }
 void set_wino4_split(int on) { g_wino4_split = on; }
+static thread_local int g_wino4_side_by_side = 1;
+int wino4_side_by_side_enabled() { return g_wino4_side_by_side; }
+void set_wino4_side_by_side(int on) { g_wino4_side_by_side = on; }
 static thread_local int g_fuse_ctc = 1;
 static thread_local int g_wino4_wave_tiles = 2;
 int wino4_wave_tiles() { return g_wino4_wave_tiles; }
@@ -263,6 +266,7 @@ using namespace ocrhip;
         ocrhip::set_current_workspace(&(h)->wino_ws);               \
         ocrhip::set_wino4_split((h)->wino4_split);                  \
         ocrhip::set_wino4_wave_tiles((h)->wino4_wave_tiles);        \
+        ocrhip::set_wino4_side_by_side((h)->wino4_side_by_side);    \
         ocrhip::set_first_layer_mfma((h)->first_layer_mfma);        \
     } while (0)
 
@@ -959,6 +963,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "wino4_wave_tiles") == 0) {
         OCR_REQUIRE(value >= 0 && value <= 2, "set_option: wino4_wave_tiles is 0, 1 or 2");
         h->wino4_wave_tiles = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "wino4_side_by_side") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: wino4_side_by_side is 0 or 1");
+        h->wino4_side_by_side = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "fuse_ctc") == 0) {

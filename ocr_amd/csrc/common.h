@@ -171,6 +171,7 @@ struct ocrhip_ctx {
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     int first_layer_mfma = 1;      // the detector's 3 -> 64 first layer on the matrix cores (1) or on the vector ALU (0); identical results
     int wino4_wave_tiles = 2;      // fused F(4x4,3x3) layers: waves own whole (block, channel) tiles of 8 x 32 outputs, inverse transform in registers: workgroups of 4 waves x 16 channels, two per CU (1); the same, and workgroups of 8 waves x 16 channels where the layer has a multiple of 128 output channels (2); or the 3x3-component split with staged partial sums on 16 x 32 tiles (0)
+    int wino4_side_by_side = 1;    // fused F(4x4,3x3) layers: a batch of images whose width leaves the 32-column tiles partly empty is tiled as one wide image, a zero column apart (1) or image by image (0)
     int wino4_split = 1;           // F(4x4,3x3) layers with >= 512 input channels: transform once into `wino_ws`, multiply from it (1) or fused (0)
     ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
     int fuse_ctc = 1;              // tokens without a logits request: class layer reduced to per-block maxima in its epilogue (1) or logits written and re-read (0)
@@ -207,7 +208,7 @@ int launch_conv_wino(const ConvLayer& L, const float* x, float* y, int B, int H,
                      const float* residual, hipStream_t s);
 // conv_wino4.hip: F(4x4,3x3) for the launches whose maps fill its 16 x 32 tiles (option "conv3x3_winograd" = 2)
 int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin);
-bool conv_wino4_fits(const ConvLayer& L, int H, int W, int pool);
+bool conv_wino4_fits(const ConvLayer& L, int B, int H, int W, int pool);
 int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H, int W, int pool, bool relu,
                       const float* residual, hipStream_t s);
 DevBuf* current_workspace();         // grow-only scratch of the handle in use on this thread (transformed tiles), or nullptr
@@ -216,6 +217,8 @@ int wino4_wave_tiles();              // option of the handle in use on this thre
 int first_layer_mfma();
 void set_first_layer_mfma(int on);
 void set_wino4_wave_tiles(int on);
+int wino4_side_by_side_enabled();    // option of the handle in use on this thread
+void set_wino4_side_by_side(int on);
 int wino4_split();                   // option of the handle in use on this thread
 void set_wino4_split(int on);
 int conv3x3_winograd();              // option of the handle in use on this thread

@@ -409,7 +409,7 @@ int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int H,
     OCR_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "conv_mfma: bad arguments B=%d H=%d W=%d", B, H, W);
     const int ks = L.ks;
     if (compute_bf16()) return launch_conv_bf16(L, x, y, B, H, W, pool, relu, up_src, up_c, s, residual);
-    if (ks == 3 && !up_src && conv3x3_winograd() == 2 && conv_wino4_fits(L, H, W, pool))
+    if (ks == 3 && !up_src && conv3x3_winograd() == 2 && conv_wino4_fits(L, B, H, W, pool))
         return launch_conv_wino4(L, x, y, B, H, W, pool, relu, residual, s);
     if (ks == 3 && L.w_wino.ptr && !up_src && conv3x3_winograd() && (int64_t)H * W * L.cin * 4 < (1ll << 31))
         return launch_conv_wino(L, x, y, B, H, W, pool, relu, residual, s);

@@ -75,6 +75,8 @@ struct Wino4Args {
     float* v;              // MODE 1 / 2: transformed tiles [tile][chunk][36][32 blocks][8], laid out like U in LDS
     int chunks_per_group;  // MODE 1: chunks a workgroup transforms
     int pair;              // 1: images of 8 rows, two of them stacked in one tile (rows 0..7 and 8..15 of its outputs)
+    int vP, vB;            // MODE 3 / 4, vP > 0: the vB images of the batch lie side by side, vP columns apart (zeros
+                           // between), and the tiles cover that one wide image; B is 1 then, W the width of one image
 };
 
 // Share of the 3x3 components (3 GR + ii, 3 GC + jj) in the 4x4 outputs of a block: Y = At_r M At_c^T with At_r the
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
     // of the two images its 8 rows between two rows of zeros, so that no block reads its neighbour image as padding.
     constexpr int NRAW = (RPX * 2 * NSUB + NT - 1) / NT;
     const int64_t img_floats = (int64_t)a.H * a.W * a.cin;
-    const int n_img = pair ? min(2, a.B - 2 * b) : 1;          // a missing second image reads as zeros (range check)
+    const int n_img = a.vP > 0 ? a.vB : (pair ? min(2, a.B - 2 * b) : 1);      // a missing second image reads as zeros (range check)
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)b * (pair ? 2 : 1) * img_floats), 0,
                                                                             (int)(n_img * img_floats * 4), 0x00020000);
     float4 ra[NRAW];
@@ -203,10 +205,17 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
         const int f = W4 ? (i == 2 ? NT + (tid & 255) : tid) : tid + i * NT;
         const int fa = f < RPX * 2 ? sub * (RPX * 2) + f : RPX * 2 * NSUB;
         const int px = f >> 1, q = f & 1;
-        const int rr = px / kRawW, gx = x0 - 1 + px % kRawW;
-        const int img = (pair && rr >= 10) ? 1 : 0;
+        const int rr = px / kRawW;
+        int gx = x0 - 1 + px % kRawW;
+        int img = (pair && rr >= 10) ? 1 : 0;
         const int gy = pair ? rr - 10 * img - 1 : y0 - 1 + rr;
-        const bool ok = fa < RPX * 2 * NSUB && (pair || W3 || rr < 18) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        bool in_x = gx >= 0;
+        if (W3 && a.vP > 0 && in_x) {          // column of the wide image -> (image, column); the gap reads as zeros
+            img = gx / a.vP;
+            gx -= img * a.vP;
+            in_x = img < a.vB;
+        }
+        const bool ok = fa < RPX * 2 * NSUB && (pair || W3 || rr < 18) && gy >= 0 && gy < a.H && in_x && gx < a.W;
         raw_src[i] = ok ? ((((img * a.H + gy) * a.W + gx) * a.cin + sub * kCK + q * 4) * 4) : (int)0x80000000;
         raw_dst[i] = (fa < RPX * 2 * NSUB) ? (sub * RB + px * kRS + q * 4) : RF;
     }
@@ -576,23 +585,42 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
             // branch (the range check looks at the vector offset only).  No 64-bit index arithmetic per store.
             constexpr int PXI = NT / (NCH / 4);                                   // pixels per iteration
             constexpr int NIT = kTW * kTH / PXI;
-            const int lp = tid / (NCH / 4), ly = lp / kTW, lx = lp % kTW;
+            static_assert(PXI == 16 && kTW % PXI == 0, "a pass covers 16 pixels of one row");
+            const int lp = tid / (NCH / 4), lx = lp;                              // the lane's pixel within a pass
             const int Y0 = (POOL == 0) ? y0 : (y0 >> 1);
-            const int64_t first = (((int64_t)b * Ho3 + Y0) * Wo3 + ox0) * a.cout + nb * NCH;     // the tile's first pixel, the block's first channel
+            const bool wide = a.vP > 0;                                           // uniform
+            // the tile's first pixel, the block's first channel (side by side images: the batch's first pixel)
+            const int64_t first = (wide ? 0 : (((int64_t)b * Ho3 + Y0) * Wo3 + ox0) * a.cout) + nb * NCH;
             const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + first), 0, 0x7fffffff, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((POOL == 0 && a.res) ? a.res + first : a.y), 0, (POOL == 0 && a.res) ? 0x7fffffff : 0, 0x00020000);
             const int pix_bytes = a.cout * 4, row_bytes = Wo3 * pix_bytes;
-            const int lane_off = ly * row_bytes + lx * pix_bytes + c4 * 16;
             const bool ch_ok = co0 + 3 < a.cout;
+            // A lane's column takes one of kTW / 16 values over the passes.  Side by side images: a column of the wide
+            // (pooled) image is (image, column); columns of the gap are dropped like those beyond the map.
+            int col_off[kTW / PXI];
+            bool col_ok[kTW / PXI];
+#pragma unroll
+            for (int j = 0; j < kTW / PXI; ++j) {
+                const int X = ox0 + j * PXI + lx;
+                if (wide) {
+                    const int po = (POOL == 1) ? (a.vP >> 1) : a.vP;
+                    const int gb = X / po, col = X - gb * po;
+                    col_ok[j] = ch_ok && gb < a.vB && col < Wo3;
+                    col_off[j] = ((gb * Ho3 + Y0) * Wo3 + col) * pix_bytes + c4 * 16;          // the launcher keeps the batch's output below 2 GB
+                } else {
+                    col_ok[j] = ch_ok && X < Wo3;
+                    col_off[j] = (j * PXI + lx) * pix_bytes + c4 * 16;
+                }
+            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int py_it = (it * PXI) / kTW, px_it = (it * PXI) % kTW;     // constants after unrolling
-                const int py = py_it + ly, pxx = px_it + lx;
+                const int py = (it * PXI) / kTW, px_it = (it * PXI) % kTW;        // constants after unrolling
+                const int pxx = px_it + lx;
                 const int by = py / PH, bx = pxx / PW;
-                const bool ok = ch_ok && Y0 + py < Ho3 && ox0 + pxx < Wo3;
-                const int voff = ok ? lane_off : (int)0x80000000;
-                const int soff = py_it * row_bytes + px_it * pix_bytes;
+                const bool ok = col_ok[px_it / PXI] && Y0 + py < Ho3;
+                const int voff = ok ? col_off[px_it / PXI] : (int)0x80000000;
+                const int soff = py * row_bytes;
                 const int rot = 16 * ((bx >> 2) & 1) + 32 * (by & 1);
                 floatx4 val = *reinterpret_cast<const floatx4*>(&lds[(lp + it * PXI) * OS + ((c4 * 4 + rot) & (NCH - 1))]) + bias4;
                 if (POOL == 0 && a.res) val += __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff, soff, 0));
@@ -789,9 +817,33 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
     return OCRHIP_OK;
 }
 
-// Whether the F(4x4,3x3) kernel serves this launch (16 x 32 tiles reasonably full; maps of 8 rows go in pairs).
-bool conv_wino4_fits(const ConvLayer& L, int H, int W, int pool) {
+// Side by side: a batch of narrow images whose width leaves the 32-column tiles partly empty is tiled as ONE wide
+// image, the images `period` columns apart with zeros between them (one column; two where columns are pooled in
+// pairs, so that every image starts on an even column).  The gap is the zero padding of both neighbours and the tiles
+// of the wide image are full.  An output then also sees the rounding noise of the neighbour image's pixels that
+// share its 6x6 patch (their exact contribution is zero): results agree with the image-by-image launch to the
+// algorithm's own error, not bit for bit.  Wave-tile modes only; the batch's input and output must fit the 2 GB of a
+// buffer descriptor.  Returns the period, 0 when the launch stays image by image.
+static int wino4_side_by_side(const ConvLayer& L, int B, int H, int W, int pool) {
+    if (!wino4_side_by_side_enabled() || !L.w_wino4b.ptr || !wino4_wave_tiles() || L.cin >= kSplitMinCin) return 0;
+    if (B < 2 || W % 32 == 0 || (L.cout & 3) != 0 || (pool == 1 && (W & 1))) return 0;
+    const int period = W + (pool == 1 ? 2 : 1);
+    const int64_t vw = (int64_t)B * period;
+    const int64_t in_bytes = (int64_t)B * H * W * L.cin * 4, out_bytes = (int64_t)B * H * W * L.cout * 4;      // (unpooled bound)
+    if (vw >= (1ll << 30) || in_bytes >= (1ll << 31) || out_bytes >= (1ll << 31)) return 0;
+    if ((vw + 31) / 32 >= (int64_t)((W + 31) / 32) * B) return 0;               // no tile saved
+    return period;
+}
+
+// Whether the F(4x4,3x3) kernel serves this launch (its tiles reasonably full; maps of 8 rows go in pairs under MODE 0).
+bool conv_wino4_fits(const ConvLayer& L, int B, int H, int W, int pool) {
     if (!L.w_wino4.ptr || (int64_t)H * W * L.cin * 4 >= (1ll << 31)) return false;
+    const int period = wino4_side_by_side(L, B, H, W, pool);
+    if (period > 0) {
+        const int64_t vw = (int64_t)B * period;
+        const double fill = (double)B * W * H / ((double)((vw + 31) / 32 * 32) * ((H + 7) / 8 * 8));
+        return fill >= 0.7;
+    }
     if (H == 8) return (double)W / ((W + 31) / 32 * 32) >= 0.7;          // one half tile, or two images stacked per tile
     const int th = (L.w_wino4b.ptr && wino4_wave_tiles()) ? 8 : 16;       // rows of the tiles the launch will use
     const double fill = (double)H * W / ((double)((H + th - 1) / th * th) * ((W + 31) / 32 * 32));
@@ -812,6 +864,7 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
     a.B = B; a.H = H; a.W = W; a.cin = L.cin; a.cout = L.cout; a.relu = relu ? 1 : 0;
     a.tiles_x = (W + 31) / 32;
     a.pair = (H == 8) ? 1 : 0;
+    a.vP = 0; a.vB = B;
     OCR_REQUIRE(!a.pair || (int64_t)2 * H * W * L.cin * 4 < (1ll << 31), "conv_wino4: image pair too large");
     a.tiles_per_image = a.tiles_x * (a.pair ? 1 : (H + 15) / 16);
     a.n_blocks_n = L.cout_pad / 64;
@@ -845,6 +898,12 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
         mode = 3;
         a.w = L.w_wino4b.as<float>();
         a.pair = 0;
+        const int period = wino4_side_by_side(L, B, H, W, pool);
+        if (period > 0) {
+            a.vP = period;
+            a.B = 1;
+            a.tiles_x = (int)(((int64_t)B * period + 31) / 32);
+        }
         a.tiles_per_image = a.tiles_x * ((H + 7) / 8);
         // layers with a multiple of 128 output channels: one workgroup of 8 waves per tile and 128 channels, so that
         // the data transform of a tile is shared by twice as many multiplications
@@ -853,7 +912,7 @@ int launch_conv_wino4(const ConvLayer& L, const float* x, float* y, int B, int H
             a.w = L.w_wino4c.as<float>();
             a.n_blocks_n = L.cout / 128;
         }
-        wgs_launch = (int64_t)a.tiles_per_image * a.n_blocks_n * B;
+        wgs_launch = (int64_t)a.tiles_per_image * a.n_blocks_n * a.B;
         OCR_REQUIRE(wgs_launch < (1ll << 31), "conv_wino4: too many workgroups");
     }
     a.v = mode == 2 ? ws->as<float>() : nullptr;

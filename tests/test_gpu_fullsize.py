@@ -42,14 +42,25 @@ def test_detector_algorithms_agree_at_full_size(setup):
 
 
 def test_page_results_do_not_depend_on_the_batch(setup):
+    """Boxes and strings of a page are the same whether it is processed alone or in a batch.  The recogniser's scores
+    are equal bit for bit when every crop is convolved on its own (`wino4_side_by_side` = 0); under the default, crops
+    of a launch share Winograd patches with their neighbours and the scores agree to rounding (a few ulp)."""
     pipe, d_img, d_maps = setup
-    both = pipe(d_img, maps_override=d_maps)
-    for b in range(2):
-        single = pipe(d_img[b:b + 1], maps_override=d_maps[b:b + 1])[0]
-        np.testing.assert_array_equal(single['boxes'], both[b]['boxes'])
-        assert single['texts'] == both[b]['texts']
-        np.testing.assert_array_equal(single['scores'], both[b]['scores'])
-        assert 150 <= len(both[b]['boxes']) <= 260                      # ~220 rendered words per page
+    for side_by_side in (1, 0):
+        pipe.ctx.set_option('wino4_side_by_side', side_by_side)
+        try:
+            both = pipe(d_img, maps_override=d_maps)
+            for b in range(2):
+                single = pipe(d_img[b:b + 1], maps_override=d_maps[b:b + 1])[0]
+                np.testing.assert_array_equal(single['boxes'], both[b]['boxes'])
+                assert single['texts'] == both[b]['texts']
+                if side_by_side:
+                    np.testing.assert_allclose(single['scores'], both[b]['scores'], rtol=2e-6, atol=0)
+                else:
+                    np.testing.assert_array_equal(single['scores'], both[b]['scores'])
+                assert 150 <= len(both[b]['boxes']) <= 260                  # ~220 rendered words per page
+        finally:
+            pipe.ctx.set_option('wino4_side_by_side', 1)
 
 
 def test_lanms_is_idempotent_on_its_output(setup):

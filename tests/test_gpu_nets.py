@@ -293,6 +293,38 @@ def test_direct_3x3_path_matches_oracle_too(ctx, shape):
         ctx.set_option('conv3x3_winograd', 3)
 
 
+@pytest.mark.parametrize('backbone', ['vgg', 'resnet'])
+def test_crops_tiled_side_by_side_match_the_oracle_and_the_image_by_image_launch(ctx, backbone):
+    """`wino4_side_by_side` (default 1): the fused F(4x4,3x3) launches tile a batch of crops whose map width is not a
+    multiple of 32 columns as one wide image with zero columns between the crops.  Widths 80 / 192 / 320 give maps of 40
+    (2x2-pooled layer: two zero columns), 20, 48 and 80 columns; 7, 5 and 3 crops give wide images that end inside a
+    tile.  Every crop must match its own oracle forward (so no crop sees its neighbours beyond rounding), and the
+    image-by-image launch to the same tolerance; the two are different computations."""
+    V = 97
+    params = nets.init_crnn_params(vocab_size=V, seed=21, backbone=backbone)
+    ctx.crnn_load_weights(params)
+    try:
+        rng = np.random.default_rng(31)
+        widths = np.array([80] * 3 + [192] * 7 + [320] * 5, dtype=np.int32)
+        crops = [rng.uniform(-1, 1, (64, int(w))).astype(np.float32) for w in widths]
+        packed = torch.from_numpy(np.concatenate([c.reshape(-1) for c in crops])).cuda()
+        side = ctx.crnn_forward_packed(packed, widths, want_logits=True)['logits'].cpu().numpy()
+        ctx.set_option('wino4_side_by_side', 0)
+        single = ctx.crnn_forward_packed(packed, widths, want_logits=True)['logits'].cpu().numpy()
+        ctx.check_errors()
+        T = ctx.seq_len(widths)
+        row0 = np.concatenate([[0], np.cumsum(T)])
+        for i, c in enumerate(crops):
+            ref = nets.crnn_forward(params, c[None, :, :, None])[0].numpy()
+            tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+            _close(side[row0[i]:row0[i + 1]], ref, rtol=1e-4, atol=tol)
+            _close(single[row0[i]:row0[i + 1]], ref, rtol=1e-4, atol=tol)
+        assert not np.array_equal(side, single)          # the side-by-side launch did run
+    finally:
+        ctx.set_option('wino4_side_by_side', 1)
+        ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=V, seed=2))
+
+
 def test_lstm_per_step_launches_match_the_persistent_layer(ctx):
     """`lstm_persistent = 0` (one launch per time step) against the default single persistent launch per layer:
     same cell arithmetic, different k order inside the matrix cores."""
