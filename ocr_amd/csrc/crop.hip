@@ -8,9 +8,11 @@
 // width first, then height, taps and weights in float32 with the index arithmetic of the filter
 // bounds in float64, each tap accumulated with a separate multiply and add (-ffp-contract=off).
 //
-// One output pixel per thread iteration; the horizontal sums of the rows a pixel needs are
-// recomputed instead of staged (2-5 taps per axis for text crops), so the kernel keeps no
-// per-crop state and has no size limit.  Bound by HBM/L2 gathers of the 3-byte source pixels:
+// A block = (crop, band of 16 output rows).  It resizes the source rows its band needs horizontally once into LDS
+// (the taps of a column computed once per block), then forms the vertical sums from LDS; a band whose source rows
+// do not fit the tables (very tall or wide crops) computes one output pixel per thread iteration and recomputes the
+// horizontal sums of the rows a pixel needs, so there is no size limit.  Same operations in the same order either
+// way.  Bound by L2 gathers of the 3-byte source pixels and the filter's float64 index arithmetic:
 // algorithmic traffic = 3 B x crop pixels read + 4 (or 2) B x 64 x Wpad written.
 #include <hip/hip_bf16.h>
 
@@ -19,6 +21,12 @@
 namespace ocrhip {
 
 namespace {
+
+constexpr int kCropRowFloats = 4096;      // horizontally resized source rows a block keeps in LDS (16 KB)
+constexpr int kCropGrayFloats = 3072;     // gray cells of those source rows before the horizontal resize (12 KB)
+constexpr int kCropMaxCols = 512;         // resized columns with their taps in LDS
+constexpr int kCropMaxRows = 32;          // output rows of a block with their taps in LDS
+constexpr int kCropTaps = 4;              // normalised weights kept per output row (the taps beyond are recomputed)
 
 struct Axis {
     float scale, support, invscale;
@@ -158,7 +166,122 @@ __global__ __launch_bounds__(256) void crop_resize_pack_kernel(const uint8_t* __
     const int rows_per_block = (out_h + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(out_h, r0 + rows_per_block);
+    if (r1 <= r0) return;
     const int total = (r1 - r0) * out_w;
+
+    // Source rows (crop coordinates) that this block's output rows take their vertical taps from
+    int ylo, yhi;
+    {
+        const int sya = min(r0, ih - 1), syb = min(r1 - 1, ih - 1);
+        if (ay.identity) {
+            ylo = sya;
+            yhi = syb + 1;
+        } else {
+            float c;
+            int lo, cnt;
+            tap_range(ay, sya, c, lo, cnt);
+            ylo = lo;
+            tap_range(ay, syb, c, lo, cnt);
+            yhi = lo + cnt;
+        }
+    }
+    // Separable path: the taps of every resized column once (s_col), the horizontally resized source rows of the band
+    // once (s_rows), then the vertical sums from LDS.  The same operations in the same order as the per-pixel path
+    // below, which recomputes a row's horizontal sum for every output row that uses it (2-3 times) and a column's taps
+    // for every row: identical results.  Bands that do not fit the tables take the per-pixel path.
+    __shared__ float s_rows[kCropRowFloats];
+    __shared__ float s_colc[kCropMaxCols], s_colt[kCropMaxCols];      // centre, sum of the tap weights
+    __shared__ int s_collo[kCropMaxCols], s_colcnt[kCropMaxCols];     // first tap, tap count
+    __shared__ float s_gray[kCropGrayFloats];                         // gray cells of the band's source rows
+    __shared__ float s_roww[kCropMaxRows * kCropTaps];                // normalised weights of a row's first taps
+    __shared__ float s_rowc[kCropMaxRows], s_rowt[kCropMaxRows];
+    __shared__ int s_rowlo[kCropMaxRows], s_rowcnt[kCropMaxRows];
+    const int nrows = yhi - ylo;
+    if (nrows > 0 && (int64_t)nrows * iw <= kCropRowFloats && iw <= kCropMaxCols && r1 - r0 <= kCropMaxRows) {      // uniform
+        if (!ax.identity) {
+            for (int sx = threadIdx.x; sx < iw; sx += blockDim.x) {
+                float center;
+                int lo, cnt;
+                tap_range(ax, sx, center, lo, cnt);
+                float tw = 0.0f;
+                for (int j = 0; j < cnt; ++j) tw = tw + tap_weight(ax, center, lo, j);
+                s_colc[sx] = center; s_colt[sx] = tw; s_collo[sx] = lo; s_colcnt[sx] = cnt;
+            }
+        }
+        if (!ay.identity && (int)threadIdx.x < r1 - r0) {
+            const int sy = min(r0 + (int)threadIdx.x, ih - 1);
+            float center;
+            int lo, cnt;
+            tap_range(ay, sy, center, lo, cnt);
+            float tw = 0.0f;
+            for (int j = 0; j < cnt; ++j) tw = tw + tap_weight(ay, center, lo, j);
+            s_rowc[threadIdx.x] = center; s_rowt[threadIdx.x] = tw; s_rowlo[threadIdx.x] = lo; s_rowcnt[threadIdx.x] = cnt;
+            for (int j = 0; j < min(cnt, kCropTaps); ++j) {
+                float w = tap_weight(ay, center, lo, j);
+                if (tw != 0.0f) w = w / tw;
+                s_roww[threadIdx.x * kCropTaps + j] = w;
+            }
+        }
+        // every cell of the band's source rows once, with independent loads in flight (the taps of neighbouring columns
+        // share cells, and a thread that fetched its cells tap by tap would wait for memory once per tap)
+        const bool gray_cached = (int64_t)nrows * cw <= kCropGrayFloats;          // uniform
+        if (gray_cached) {
+#pragma unroll 4
+            for (int i = threadIdx.x; i < nrows * cw; i += blockDim.x) s_gray[i] = src.at(ylo + i / cw, i % cw);
+        }
+        __syncthreads();
+        auto cell = [&](int yy, int x) { return gray_cached ? s_gray[(yy - ylo) * cw + x] : src.at(yy, x); };
+        for (int i = threadIdx.x; i < nrows * iw; i += blockDim.x) {
+            const int yy = ylo + i / iw, sx = i % iw;
+            float acc;
+            if (ax.identity) {
+                acc = cell(yy, sx);
+            } else {
+                const float center = s_colc[sx], tw = s_colt[sx];
+                const int lo = s_collo[sx], cnt = s_colcnt[sx];
+                acc = 0.0f;
+                for (int j = 0; j < cnt; ++j) {
+                    float w = tap_weight(ax, center, lo, j);
+                    if (tw != 0.0f) w = w / tw;
+                    const float term = cell(yy, lo + j) * w;
+                    acc = (j == 0) ? term : (acc + term);
+                }
+            }
+            s_rows[i] = acc;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int ry = i / out_w, ox = i % out_w;
+            const int oy = r0 + ry;
+            const int sy = min(oy, ih - 1), sx = min(ox, iw - 1);     // repeat_last: right, then bottom
+            float v;
+            if (ay.identity) {
+                v = s_rows[(sy - ylo) * iw + sx];
+            } else {
+                const float center = s_rowc[ry], tw = s_rowt[ry];
+                const int lo = s_rowlo[ry], cnt = s_rowcnt[ry];
+                v = 0.0f;
+                for (int j = 0; j < cnt; ++j) {
+                    float w;
+                    if (j < kCropTaps) {
+                        w = s_roww[ry * kCropTaps + j];
+                    } else {
+                        w = tap_weight(ay, center, lo, j);
+                        if (tw != 0.0f) w = w / tw;
+                    }
+                    const float term = s_rows[(lo + j - ylo) * iw + sx] * w;
+                    v = (j == 0) ? term : (v + term);
+                }
+            }
+            v = (v - 0.5f) / 0.5f;
+            const int64_t o = dst + (int64_t)oy * out_w + ox;
+            if (BF16)
+                reinterpret_cast<__hip_bfloat16*>(packed)[o] = __float2bfloat16(v);
+            else
+                reinterpret_cast<float*>(packed)[o] = v;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int oy = r0 + i / out_w, ox = i % out_w;
         const int sy = min(oy, ih - 1), sx = min(ox, iw - 1);     // repeat_last: right, then bottom
