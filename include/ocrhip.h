@@ -70,8 +70,12 @@ int ocrhip_destroy(ocrhip_handle h);
  *   sum per layer) for the launches whose feature map fills that kernel's 16x32 tiles, F(2x2,3x3) for the others;
  *   1: F(2x2,3x3) everywhere (2.25x fewer multiplications, results within float32 rounding of the direct sum);
  *   0: a direct implicit GEMM (a float32 fma chain over the taps and channels).
- *   "lstm_persistent": 1 (default) runs the recurrence of a BiLSTM layer as one launch of persistent workgroups
- *   (W_hh resident in LDS, h_t handed over through L2); 0 launches one kernel per time step.  Same arithmetic.
+ *   "lstm_persistent": 1 and 2 (default) run the recurrence of a BiLSTM layer as one launch of persistent workgroups
+ *   (W_hh resident in LDS, h_t handed over through memory); 0 launches one kernel per time step.  1: the four waves of
+ *   a workgroup share passes of 112 sequences (h staged through LDS, one counter per pass).  2: where a workgroup has
+ *   at least 8 blocks of 16 sequences (about 2000 crops on 256 compute units), its eight waves own blocks with all gate
+ *   columns each, read h straight from memory and hand over per block, without any barrier; smaller batches as 1.
+ *   3: the independent waves whatever the batch size.  Same arithmetic in all of them, 1 / 2 / 3 bit-identical
  *   (hidden sizes other than 256 always take the per-step kernel).  A persistent launch needs the whole GPU: its
  *   workgroups wait for each other, so launches of one process are chained (one at a time per device), and if another
  *   process or stream holds compute units for seconds a wait gives up, the kernel leaves, and the error surfaces through

@@ -31,7 +31,7 @@ struct Bf16Scope {
     explicit Bf16Scope(int dtype) { set_compute_bf16(dtype == OCRHIP_BF16 ? 1 : 0); }
     ~Bf16Scope() { set_compute_bf16(0); }
 };
-static thread_local int g_lstm_persistent = 1;
+static thread_local int g_lstm_persistent = 2;
 int lstm_persistent() { return g_lstm_persistent; }
 void set_lstm_persistent(int on) { g_lstm_persistent = on; }
 static thread_local int g_lstm_debug_drop = 0;
@@ -941,7 +941,7 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "lstm_persistent") == 0) {
-        OCR_REQUIRE(value == 0 || value == 1, "set_option: lstm_persistent is 0 or 1");
+        OCR_REQUIRE(value >= 0 && value <= 3, "set_option: lstm_persistent is 0, 1, 2 or 3");
         h->lstm_persistent = value;
         return OCRHIP_OK;
     }

@@ -374,6 +374,195 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
     }
 }
 
+// ---- The same layer with independent waves (`lstm_persistent` = 2).
+// The workgroup above splits the gate columns over its waves, so all of them need the h rows of the whole pass: h goes
+// through LDS and every k chunk passes a barrier, the four waves walk through a pass in lockstep, and whatever one of
+// them waits for (the partners' counter, the first h loads of a pass, the acknowledgement of its h stores) all of them
+// wait for, on SIMDs that hold one wave each.  Here a wave owns BLOCKS OF 16 SEQUENCES instead, with all 128 gate
+// columns of the workgroup's 32 units: 8 accumulator tiles of 16x16.  Its A operand - its own 16 rows of h_{t-1} - comes
+// straight from memory in the layout the matrix instruction reads (lane (row, k group) loads 16 bytes per 16 k
+// values), W_hh is read from the same LDS image, and nothing is shared between waves after the image is built: no
+// barrier, no staging buffer.  A workgroup has 8 waves, two per SIMD, each at its own point of its own block, so one
+// wave's waits are the other's issue time.  All four gates of an element land in one lane (column tile c holds gate
+// c & 3 of units 16 (c >> 2) + lane % 16), so the cell update needs no lane exchange.  The hand-over is per block: the
+// 8 workgroups of a (direction, sequence group) count up one counter per block, and a wave waits for its block's
+// counter only.  Same k order inside every accumulator and the same cell arithmetic as the kernel above:
+// bit-identical results.
+constexpr int kBlockRows = 16;
+constexpr int kDeviceScope = 16;    // cache policy bits of a buffer load: sc1 = device scope, what an agent-scope atomic load carries
+
+template <bool RAGGED>
+__global__ __launch_bounds__(512, 1) void lstm_layer_waves_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ws = lds;                 // [row R = 16 c + j: gate c & 3 of unit 16 (c >> 2) + j][64 slots of 16 bytes, slot s stored at s ^ (R & 15)]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lg = lane >> 4;
+    const int G = a.G, n = a.n;
+
+    int sg, ub;
+    if ((2 * G) % 8 == 0) {          // workgroups sharing (direction, g) on one XCD, see above
+        const int q = blockIdx.x & 7, r = blockIdx.x >> 3;
+        sg = q * (2 * G / 8) + (r >> 3);
+        ub = r & 7;
+    } else {
+        sg = blockIdx.x >> 3;
+        ub = blockIdx.x & 7;
+    }
+    const int dir = sg / G, g = sg % G;
+    const int u0 = ub * 32;
+    unsigned* counters = a.counters + sg * kMaxPass;
+
+    {
+        const float* W = a.whh[dir];
+        for (int f = tid; f < 128 * 64; f += 512) {
+            const int R = f >> 6, c = f & 63;
+            const int ct = R >> 4, j = R & 15;
+            const float4 v = *reinterpret_cast<const float4*>(W + ((int64_t)(ct & 3) * kH + u0 + 16 * (ct >> 2) + j) * kH + c * 4);
+            *reinterpret_cast<float4*>(&Ws[(R * 64 + (c ^ (R & 15))) * 4]) = v;
+        }
+    }
+    __syncthreads();                 // the only barrier
+
+    // row j of block rb is the sequence of descending-length rank d = (rb * 16 + j) * G + g
+    const float* wrow = Ws + l16 * 256;          // + ct * 16 * 256 + ((4 j + lg) ^ l16) * 4
+
+    for (int t = 0; t < a.T; ++t) {
+        const int n_act = RAGGED ? a.step_active[t] : n;              // sequences still running, over all groups
+        const int act_local = (n_act > g) ? (n_act - g + G - 1) / G : 0;      // prefix of this group's rows
+        if (act_local == 0) break;
+        const int blocks_here = (act_local + kBlockRows - 1) / kBlockRows;
+        const float* hprev = a.hbuf + ((int64_t)((t + 1) & 1) * 2 + dir) * n * kH;
+        float* hnext = a.hbuf + ((int64_t)(t & 1) * 2 + dir) * n * kH;
+
+        for (int rb = wave; rb < blocks_here; rb += 8) {
+            const int rows_here = min(kBlockRows, act_local - rb * kBlockRows);
+            // the lane's elements: rows 4 lg + v (v = 0..3) of the block, units l16 and 16 + l16 of the workgroup's 32
+            int sv[4], rowv[4];
+            float xwv[4][2][4], cpv[4][2];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int j = 4 * lg + v;
+                const int s = max(n - 1 - ((rb * kBlockRows + j) * G + g), 0);
+                sv[v] = (j < rows_here) ? s : -1;
+                int Ts, r0;
+                if (RAGGED) {
+                    Ts = a.seq_T[s];
+                    r0 = a.seq_row0[s];
+                } else {
+                    Ts = a.T;
+                    r0 = s * a.T;
+                }
+                rowv[v] = r0 + (dir ? (Ts - 1 - t) : t);
+            }
+            floatx4 acc[8];
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+            if (t > 0) {
+                // wait until the 8 workgroups of (direction, g) have published this block of h_{t-1}
+                const unsigned want = 8u * (unsigned)t;
+                int spins = 0;
+                bool gave_up = false;
+                while (__hip_atomic_load(counters + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    const bool partner_gave_up = (spins & 255) == 0 && __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (spins >= a.spin_cap || partner_gave_up) {
+                        gave_up = true;
+                        break;
+                    }
+                }
+                if (gave_up) {               // uniform in the wave: every lane read the same words
+                    if (lane == 0) __hip_atomic_fetch_or(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;                  // no barrier follows: the other waves run into the error word themselves
+                }
+                // the wave's 16 rows of h_{t-1}: lane (row l16, k group lg) holds k = 16 j + 4 lg .. + 3 for j = 0..15
+                asm volatile("" ::: "memory");          // the loads below stay behind the wait
+                const int dA = (rb * kBlockRows + l16) * G + g;
+                // 16-byte loads with device scope (the cache policy of the atomic loads above: served from where all
+                // XCDs agree), all 16 of a block in flight at once: at ~1.4 TB/s for the whole device these loads are
+                // bound by how many of them are outstanding, not by bandwidth.  Rows beyond the active ones carry an
+                // out-of-range offset and read as zeros.
+                const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hprev, 0, n * (kH * 4), 0x00020000);
+                const int h_off = (l16 < rows_here) ? (max(n - 1 - dA, 0) * kH + lg * 4) * 4 : (int)0x80000000;
+                float4 ha[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    ha[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, h_off, 64 * j, kDeviceScope));
+                // what the cell update needs besides the product, requested behind the h loads
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu) {
+                        const int unit = u0 + 16 * uu + l16;
+                        const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
+                        xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
+                        cpv[v][uu] = a.cbuf[((int64_t)dir * n + max(sv[v], 0)) * kH + unit];
+                    }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    // W_hh operands of the step: the SIMD's other wave covers their latency
+                    float4 b4[8];
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) b4[ct] = *reinterpret_cast<const float4*>(wrow + ct * (16 * 256) + (((4 * j + lg) ^ l16) * 4));
+                    const float4 av = ha[j];
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b4[ct].x, acc[ct], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b4[ct].y, acc[ct], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b4[ct].z, acc[ct], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b4[ct].w, acc[ct], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu) {
+                        const int unit = u0 + 16 * uu + l16;
+                        const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
+                        xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
+                        cpv[v][uu] = 0.0f;
+                    }
+            }
+            // cell update: register v of column tile c = gate c & 3 of unit 16 (c >> 2) + l16, row 4 lg + v
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu) {
+                    float c, hval;
+                    lstm_cell(xwv[v][uu][0] + acc[4 * uu + 0][v], xwv[v][uu][1] + acc[4 * uu + 1][v], xwv[v][uu][2] + acc[4 * uu + 2][v],
+                              xwv[v][uu][3] + acc[4 * uu + 3][v], cpv[v][uu], c, hval);
+                    cpv[v][uu] = c;
+                    xwv[v][uu][0] = hval;
+                }
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu)
+                    if (sv[v] >= 0) store_h(hnext + (int64_t)sv[v] * kH + u0 + 16 * uu + l16, xwv[v][uu][0]);
+            // publish this block of h_t: the wave's stores have reached the coherence point, then its count
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+            const bool dropped = a.debug_drop && sg == 0 && ub == 7 && t == 0;
+            if (lane == 0 && !dropped) __hip_atomic_fetch_add(counters + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu) {
+                    if (sv[v] < 0) continue;
+                    const int unit = u0 + 16 * uu + l16;
+                    a.cbuf[((int64_t)dir * n + sv[v]) * kH + unit] = cpv[v][uu];
+                    a.out[(int64_t)rowv[v] * (2 * kH) + dir * kH + unit] = xwv[v][uu][0];
+                }
+        }
+    }
+}
+
 }  // namespace
 
 // One bidirectional LSTM layer over n sequences in one launch of persistent workgroups.  `counters` must hold
@@ -410,6 +599,12 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
         OCR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         int per_cu = 0;
         OCR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_layer_kernel<true>), 256, kLdsBytes));
+        // the kernel of independent waves: workgroups of 8 waves with the W_hh image alone in LDS
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kWFloats * 4));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kWFloats * 4));
+        int per_cu_w = 0;
+        OCR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, reinterpret_cast<const void*>(&lstm_layer_waves_kernel<true>), 512, kWFloats * 4));
+        per_cu = std::min(per_cu, per_cu_w);
         const int resident = per_cu * prop.multiProcessorCount;
         mg = (resident >= 16) ? std::min(16, resident / 16) : -1;
     }
@@ -438,7 +633,16 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
     OCR_HIP_CHECK(hipMemsetAsync(counters, 0, kLstmCounterCount * sizeof(unsigned), s));
     // a plain launch: the grid is sized to what the device holds at once (checked above), which is all the hand-over
     // needs; the cooperative-launch entry point, which performs the same check, crashes the profiler at process exit
-    if (seq_T)
+    // independent waves (blocks of 16 sequences, one counter per block) when the counters reach; else passes of 112
+    // (a group with fewer than 8 blocks would leave waves idle: the pass kernel, whose waves share every row, is faster)
+    const int blocks = ((n + a.G - 1) / a.G + kBlockRows - 1) / kBlockRows;
+    const bool waves = ((lstm_persistent() == 2 && blocks >= 8) || lstm_persistent() == 3) && blocks <= kMaxPass;
+    if (waves) {
+        if (seq_T)
+            hipLaunchKernelGGL(lstm_layer_waves_kernel<true>, dim3(16 * a.G), dim3(512), kWFloats * 4, s, a);
+        else
+            hipLaunchKernelGGL(lstm_layer_waves_kernel<false>, dim3(16 * a.G), dim3(512), kWFloats * 4, s, a);
+    } else if (seq_T)
         hipLaunchKernelGGL(lstm_layer_kernel<true>, dim3(16 * a.G), dim3(256), kLdsBytes, s, a);
     else
         hipLaunchKernelGGL(lstm_layer_kernel<false>, dim3(16 * a.G), dim3(256), kLdsBytes, s, a);

@@ -112,7 +112,9 @@ class HipContext:
     def set_option(self, name, value):
         """'conv3x3_winograd': 2 (default) Winograd F(4x4,3x3) where the map fills its tiles and F(2x2,3x3) elsewhere,
         1 F(2x2,3x3) for all wide 3x3 convolutions, 0 direct implicit GEMM.
-        'lstm_persistent': 1 (default) one persistent launch per BiLSTM layer, 0 one launch per time step.
+        'lstm_persistent': 2 (default) one persistent launch per BiLSTM layer (independent waves on blocks of 16
+        sequences for large batches, workgroup-wide passes otherwise), 1 passes always, 3 independent waves always,
+        0 one launch per time step.
         'wino4_split': 1 (default) F(4x4,3x3) layers with >= 512 input channels as transform kernel + multiply kernel,
         0 fused.
         'flat_gemm': 1 (default) Dense layers / LSTM input projections / 2x2 convolutions on the 256 x 128 flat GEMM,

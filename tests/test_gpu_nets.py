@@ -3,6 +3,8 @@ C ABI.  Tolerance: 1e-4 relative on the maps / logits (different summation order
 import numpy as np
 import pytest
 
+LSTM_DEFAULT = 2          # the library's default `lstm_persistent`
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip('torch')
@@ -206,7 +208,8 @@ def test_greedy_tokens_without_logits_equal_the_decoding_of_the_logits(ctx, V):
         ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=97, seed=2))
 
 
-def test_lstm_handover_timeout_is_an_error_not_output(ctx):
+@pytest.mark.parametrize('kernel', [1, 3])
+def test_lstm_handover_timeout_is_an_error_not_output(ctx, kernel):
     """A persistent recurrence whose workgroups cannot hand over (here: one of them withholds its first hand-over
     through the test hook) must fail the call loudly, and the handle must work again afterwards."""
     from ocr_amd._lib import OcrHipError
@@ -215,6 +218,7 @@ def test_lstm_handover_timeout_is_an_error_not_output(ctx):
     x = torch.from_numpy(np.random.default_rng(0).uniform(-1, 1, (40, 64, 128, 1)).astype(np.float32)).cuda()
     good = ctx.crnn_forward(x, want_logits=True)['logits'].cpu().numpy()
     ctx.check_errors()
+    ctx.set_option('lstm_persistent', kernel)          # workgroup-wide passes / independent waves
     ctx.set_option('lstm_debug_drop_handover', 1)
     try:
         ctx.crnn_forward(x, want_logits=True)
@@ -228,6 +232,7 @@ def test_lstm_handover_timeout_is_an_error_not_output(ctx):
             ctx.crnn_forward(x, want_logits=True)
     finally:
         ctx.set_option('lstm_debug_drop_handover', 0)
+        ctx.set_option('lstm_persistent', LSTM_DEFAULT)
     again = ctx.crnn_forward(x, want_logits=True)['logits'].cpu().numpy()
     ctx.check_errors()
     np.testing.assert_array_equal(again, good)
@@ -339,11 +344,45 @@ def test_lstm_per_step_launches_match_the_persistent_layer(ctx):
     try:
         b = ctx.crnn_forward_packed(packed, widths, want_logits=True)
     finally:
-        ctx.set_option('lstm_persistent', 1)
+        ctx.set_option('lstm_persistent', LSTM_DEFAULT)
     torch.cuda.synchronize()
     la, lb = a['logits'].cpu().numpy(), b['logits'].cpu().numpy()
     _close(la, lb, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(lb).max())))
     np.testing.assert_array_equal(a['lengths'].cpu().numpy(), b['lengths'].cpu().numpy())
+
+
+def test_lstm_independent_waves_equal_the_pass_kernel_bit_for_bit(ctx):
+    """`lstm_persistent = 2 / 3`: waves own blocks of 16 sequences with all gate columns, h straight from memory, one
+    hand-over counter per block, no barrier - against `lstm_persistent = 1` (workgroup-wide passes of 112 sequences
+    through LDS).  Same k order in every accumulator and the same cell arithmetic: identical logits.  Ragged batch with
+    partial blocks (5, 40, 150, 3, 1 sequences per length) and a uniform batch whose count is not a multiple of 16."""
+    V = 97
+    params = nets.init_crnn_params(vocab_size=V, seed=11)
+    ctx.crnn_load_weights(params)
+    rng = np.random.default_rng(6)
+    widths = np.array([64] * 5 + [96] * 40 + [128] * 150 + [256] * 3 + [512], dtype=np.int32)
+    packed = torch.from_numpy(rng.uniform(-1, 1, int(64 * widths.sum())).astype(np.float32)).cuda()
+    x = torch.from_numpy(rng.uniform(-1, 1, (37, 64, 160, 1)).astype(np.float32)).cuda()
+    out = {}
+    try:
+        for opt in (1, 3):          # 3: independent waves whatever the batch size (2 takes them from 8 blocks per workgroup on)
+            ctx.set_option('lstm_persistent', opt)
+            out[opt] = (ctx.crnn_forward_packed(packed, widths, want_logits=True)['logits'].cpu().numpy(),
+                        ctx.crnn_forward(x, want_logits=True)['logits'].cpu().numpy())
+            ctx.check_errors()
+        # a batch large enough for the default to pick the wave kernel by itself: 16 groups x 9 blocks
+        big = torch.from_numpy(rng.uniform(-1, 1, (2200, 64, 64, 1)).astype(np.float32)).cuda()
+        for opt in (1, 2):
+            ctx.set_option('lstm_persistent', opt)
+            out['big', opt] = ctx.crnn_forward(big, want_logits=True)['logits'].cpu().numpy()
+            ctx.check_errors()
+    finally:
+        ctx.set_option('lstm_persistent', LSTM_DEFAULT)
+    np.testing.assert_array_equal(out[3][0], out[1][0])
+    np.testing.assert_array_equal(out[3][1], out[1][1])
+    np.testing.assert_array_equal(out['big', 2], out['big', 1])
+    ref = nets.crnn_forward(params, x.cpu().numpy()[:3]).numpy()
+    _close(out[3][1][:3], ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
 
 
 def test_flat_gemm_matches_the_convolution_kernel(ctx):
