@@ -29,7 +29,7 @@ def stage_name(kernel):
         kind = {'0': '', '2': '_mul', '3': '_h', '4': '_h'}[m.group(2)]
         return 'conv_wino4%s_f32<n%s,pool%s,tile%sx32>' % (kind, '128' if m.group(2) == '4' else '64', m.group(1),
                                                            '8' if m.group(2) in '34' else '16')
-    m = re.search(r'lstm_layer_kernel', kernel)
+    m = re.search(r'lstm_layer(_waves)?_kernel', kernel)
     if m:
         return 'lstm_layer'
     m = re.search(r'conv_wino_f32_kernel<(\d+), (\d+)>', kernel)
