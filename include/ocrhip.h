@@ -82,10 +82,11 @@ int ocrhip_destroy(ocrhip_handle h);
  *   ocrhip_check_errors / the next ocrhip_crnn_forward* call on the handle (OCRHIP_EHIP, "lstm hand-over timed out").
  *   "lstm_debug_drop_handover": test hook, 0 (default) | 1: one workgroup of the persistent recurrence withholds its
  *   first hand-over and waits give up after 4096 spins, which exercises the time-out path above.
- *   "wino4_split": 1 (default) runs the F(4x4,3x3) layers with >= 512 input channels as two kernels (transform the
- *   input tiles once into a workspace, then multiply from it); 0 keeps them fused (every 64-channel workgroup transforms
- *   its tile itself).  Same arithmetic, identical results.
- *   "wino4_wave_tiles": how the fused F(4x4,3x3) launches (fewer than 512 input channels, or all with wino4_split = 0)
+ *   "wino4_split": 0 (default) runs every F(4x4,3x3) layer fused (a workgroup transforms its input tile itself); 1 runs
+ *   the layers with >= 512 input channels as two kernels (transform the input tiles once into a workspace of the
+ *   handle, then multiply from it: no LDS, barrier or vector arithmetic in the multiply loop).  Results agree to the
+ *   order of the inverse transform's additions.
+ *   "wino4_wave_tiles": how the fused F(4x4,3x3) launches (all layers; with wino4_split = 1 those below 512 input channels)
  *   divide a tile between the waves.  1: tiles of 8 x 32 outputs, two workgroups of 4 waves x 16 channels per compute
  *   unit, every wave owns whole (block, channel) tiles (16x16x4 matrix instructions, all 36 Winograd components in one
  *   lane), so the inverse transform and the max-pool run in registers and a tile passes one barrier on its way out.

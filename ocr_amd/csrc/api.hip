@@ -43,7 +43,7 @@ void set_conv3x3_winograd(int on) { g_conv3x3_winograd = on; }
 static thread_local DevBuf* g_workspace = nullptr;
 DevBuf* current_workspace() { return g_workspace; }
 void set_current_workspace(DevBuf* ws) { g_workspace = ws; }
-static thread_local int g_wino4_split = 1;
+static thread_local int g_wino4_split = 0;
 int wino4_split() { return g_wino4_split; }
 void set_wino4_split(int on) { g_wino4_split = on; }
 static thread_local int g_wino4_side_by_side = 1;

@@ -172,7 +172,7 @@ struct ocrhip_ctx {
     int first_layer_mfma = 1;      // the detector's 3 -> 64 first layer on the matrix cores (1) or on the vector ALU (0); identical results
     int wino4_wave_tiles = 2;      // fused F(4x4,3x3) layers: waves own whole (block, channel) tiles of 8 x 32 outputs, inverse transform in registers: workgroups of 4 waves x 16 channels, two per CU (1); the same, and workgroups of 8 waves x 16 channels where the layer has a multiple of 128 output channels (2); or the 3x3-component split with staged partial sums on 16 x 32 tiles (0)
     int wino4_side_by_side = 1;    // fused F(4x4,3x3) layers: a batch of images whose width leaves the 32-column tiles partly empty is tiled as one wide image, a zero column apart (1) or image by image (0)
-    int wino4_split = 1;           // F(4x4,3x3) layers with >= 512 input channels: transform once into `wino_ws`, multiply from it (1) or fused (0)
+    int wino4_split = 0;           // F(4x4,3x3) layers with >= 512 input channels: fused like the others (0), or transform once into `wino_ws` and multiply from it (1)
     ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
     int fuse_ctc = 1;              // tokens without a logits request: class layer reduced to per-block maxima in its epilogue (1) or logits written and re-read (0)
     int flat_gemm = 1;             // 1x1 / 2x2 layers on the 256 x 128 flat GEMM (1) or on the implicit-GEMM convolution kernel (0)

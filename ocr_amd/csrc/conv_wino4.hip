@@ -62,7 +62,7 @@ constexpr int kLoopFloats4 = 2 * kLoopFloats3;
 constexpr int kStageFloats4 = 8 * 32 * (128 + 4);
 constexpr int kLdsBytes4 = 4 * (kLoopFloats4 > kStageFloats4 ? kLoopFloats4 : kStageFloats4);
 constexpr int kWChunkFloats = 36 * 2 * 64 * 4;  // transformed filters of one chunk of one 64-channel block
-constexpr int kSplitMinCin = 512;               // layers at least this deep run as transform kernel + multiply kernel
+constexpr int kSplitMinCin = 512;               // layers at least this deep run as transform kernel + multiply kernel under `wino4_split`
 
 struct Wino4Args {
     const float* x;        // (B,H,W,cin)
@@ -776,7 +776,7 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
         }
     OCR_TRY(L.w_wino4.reserve(w.size() * sizeof(float)));
     OCR_HIP_CHECK(hipMemcpy(L.w_wino4.ptr, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (cin < kSplitMinCin) {
+    {
         // the same transformed filters in the layout of MODE 3 (the fused layers):
         // [n block][k chunk][f2 = f / 2][cq][lane = 16 q + j][t = 2 (f % 2) + step]: output channel 64 nblock + 16 cq + j,
         // input channel 8 kchunk + 2 q + step
@@ -825,7 +825,7 @@ int prepare_conv_wino4(ConvLayer& L, const float* w_oihw, int cout, int cin) {
 // algorithm's own error, not bit for bit.  Wave-tile modes only; the batch's input and output must fit the 2 GB of a
 // buffer descriptor.  Returns the period, 0 when the launch stays image by image.
 static int wino4_side_by_side(const ConvLayer& L, int B, int H, int W, int pool) {
-    if (!wino4_side_by_side_enabled() || !L.w_wino4b.ptr || !wino4_wave_tiles() || L.cin >= kSplitMinCin) return 0;
+    if (!wino4_side_by_side_enabled() || !L.w_wino4b.ptr || !wino4_wave_tiles() || (wino4_split() && L.cin >= kSplitMinCin)) return 0;
     if (B < 2 || W % 32 == 0 || (L.cout & 3) != 0 || (pool == 1 && (W & 1))) return 0;
     const int period = W + (pool == 1 ? 2 : 1);
     const int64_t vw = (int64_t)B * period;

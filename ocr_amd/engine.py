@@ -115,8 +115,8 @@ class HipContext:
         'lstm_persistent': 2 (default) one persistent launch per BiLSTM layer (independent waves on blocks of 16
         sequences for large batches, workgroup-wide passes otherwise), 1 passes always, 3 independent waves always,
         0 one launch per time step.
-        'wino4_split': 1 (default) F(4x4,3x3) layers with >= 512 input channels as transform kernel + multiply kernel,
-        0 fused.
+        'wino4_split': 0 (default) every F(4x4,3x3) layer fused, 1 layers with >= 512 input channels as transform kernel +
+        multiply kernel.
         'flat_gemm': 1 (default) Dense layers / LSTM input projections / 2x2 convolutions on the 256 x 128 flat GEMM,
         0 on the implicit-GEMM convolution kernel."""
         check(self.lib.ocrhip_set_option(self._h, name.encode(), int(value)))

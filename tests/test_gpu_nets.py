@@ -264,9 +264,12 @@ def test_direct_3x3_path_matches_oracle_too(ctx, shape):
             maps[opt] = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
             got = ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True)['logits'].cpu().numpy()
             _close(got, cref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(cref).max())))
-        ctx.set_option('wino4_split', 0)          # deep layers fused instead of transform kernel + multiply kernel
-        fused = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
-        ctx.set_option('wino4_split', 1)
+        ctx.set_option('wino4_split', 1)          # deep layers as transform kernel + multiply kernel instead of fused
+        split = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
+        ctx.set_option('wino4_wave_tiles', 0)     # ... against the fused kernel with the multiply kernel's division of the work
+        split_ref = ctx.east_forward(torch.from_numpy(img).cuda()).cpu().numpy()
+        ctx.set_option('wino4_split', 0)
+        ctx.set_option('wino4_wave_tiles', 2)
         # the other division of the fused 4x4 kernel's work: 3x3 components per wave on full tiles instead of whole
         # (block, channel) tiles per wave on half tiles
         ctx.set_option('wino4_wave_tiles', 0)
@@ -279,9 +282,10 @@ def test_direct_3x3_path_matches_oracle_too(ctx, shape):
                   ctx.crnn_forward(torch.from_numpy(x).cuda(), want_logits=True)['logits'].cpu().numpy())
     finally:
         ctx.set_option('conv3x3_winograd', 2)
-        ctx.set_option('wino4_split', 1)
+        ctx.set_option('wino4_split', 0)
         ctx.set_option('wino4_wave_tiles', 2)
-    np.testing.assert_array_equal(fused, maps[2])     # same products in the same order
+    _close(split, ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(split_ref, parts[0])          # the multiply kernel: same products in the same order
     np.testing.assert_array_equal(narrow[0], maps[2])
     np.testing.assert_array_equal(narrow[1], got)
     _close(parts[0], ref, rtol=1e-4, atol=1e-5)                  # another order of the inverse transform's additions
