@@ -47,6 +47,7 @@ struct Image {
     int* act;             // active indices (input order)
     int* act2;
     float4* bounds;       // per 64-entry tile of act: (min x1, min y1, max x2, max y2)
+    float4* bounds2;      // per tile two such rectangles: its entries before and from its largest jump (see build_bounds)
     int* kept;            // indices of the kept boxes
     int* hdr;             // [0] = loop condition published by the split first iteration
     float* wcur;          // weighted merge: weight of every box (its score plus the weights of what it absorbed)
@@ -83,17 +84,44 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// bounds of every 64-entry tile of the active list
+__device__ __forceinline__ bool rects_meet(const float4 p, const float4 q) {
+    return (p.x <= q.z) && (q.x <= p.z) && (p.y <= q.w) && (q.y <= p.w);
+}
+
+// Bounds of every 64-entry tile of the active list, and of its two parts.  A tile of the cell-sorted list nearly always
+// holds the last candidates of one word and the first of the next one; when the two are far apart the tile's bounds
+// cover everything between them, and a target tile's pair tests run over every box inside its bounds.  So the tile is
+// also cut at the largest jump between the centres of consecutive entries, and both parts get bounds of their own:
+// a box that meets neither part cannot overlap any box of the tile.
 __device__ void build_bounds(const Image& im, const float4* boxes, const int* act, int n_act) {
     n_act = __builtin_amdgcn_readfirstlane(n_act);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ntiles = (n_act + 63) >> 6;
     for (int T = wave; T < ntiles; T += kWaves) {
         const int e = T * 64 + lane;
+        const bool valid = e < n_act;
         float4 b = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
-        if (e < n_act) b = boxes[act[e]];
+        if (valid) b = boxes[act[e]];
         const float x1 = wave_min(b.x), y1 = wave_min(b.y), x2 = wave_max(b.z), y2 = wave_max(b.w);
         if (lane == 0) im.bounds[T] = make_float4(x1, y1, x2, y2);
+        // jump from the previous entry (0 for the first entry and beyond the list); the cut goes before the entry with
+        // the largest one (the lowest such entry; entry 32 when all centres coincide)
+        const float cx = b.x + b.z, cy = b.y + b.w;
+        const float px = __shfl_up(cx, 1, 64), py = __shfl_up(cy, 1, 64);
+        float jump = (valid && lane > 0) ? fabsf(cx - px) + fabsf(cy - py) : 0.0f;
+        if (!(jump == jump)) jump = 0.0f;
+        const float top = wave_max(jump);
+        const unsigned long long at = __ballot(jump == top && lane > 0);
+        const int cut = (top > 0.0f && at) ? __builtin_ctzll(at) : 32;
+        const bool first = lane < cut;
+        const float4 inf = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+        const float4 ba = first ? b : inf, bb = first ? inf : b;
+        const float ax1 = wave_min(ba.x), ay1 = wave_min(ba.y), ax2 = wave_max(ba.z), ay2 = wave_max(ba.w);
+        const float bx1 = wave_min(bb.x), by1 = wave_min(bb.y), bx2 = wave_max(bb.z), by2 = wave_max(bb.w);
+        if (lane == 0) {
+            im.bounds2[2 * T] = make_float4(ax1, ay1, ax2, ay2);
+            im.bounds2[2 * T + 1] = make_float4(bx1, by1, bx2, by2);
+        }
     }
 }
 
@@ -118,6 +146,7 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
         const unsigned fl_t = t_valid ? im.flags[t] : 0u;
         const float area_t = box_area(bt);
         const float4 tb = im.bounds[T];
+        const float4 tba = im.bounds2[2 * T], tbb = im.bounds2[2 * T + 1];      // the tile's two parts
 
         bool has_upper = false, has_lower = false, hit_by_clean = false;
         float mnx = INFINITY, mny = INFINITY, mxx = 0.f, mxy = 0.f;     // union accumulators
@@ -134,7 +163,11 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
                 bool c = S < ntiles;
                 if (c && cull) {
                     const float4 sb = im.bounds[S];
-                    c = (sb.x <= tb.z) && (tb.x <= sb.z) && (sb.y <= tb.w) && (tb.y <= sb.w);
+                    c = rects_meet(sb, tb);
+                    if (c) {          // part by part: the union of two distant parts meets much that neither part does
+                        const float4 sa = im.bounds2[2 * S], sbb = im.bounds2[2 * S + 1];
+                        c = rects_meet(sa, tba) || rects_meet(sa, tbb) || rects_meet(sbb, tba) || rects_meet(sbb, tbb);
+                    }
                 }
                 cand = __ballot(c);
             }
@@ -150,9 +183,9 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
                 const unsigned fl_l = u_valid ? im.flags[u_l] : 0u;
                 const float area_l = box_area(bu_l);
                 const float w_l = (weighted && u_valid) ? im.wcur[u_l] : 0.f;
-                // only the boxes of S that reach into the bounds of tile T can overlap one of its boxes (thr > 0)
+                // only the boxes of S that reach into the bounds of one of tile T's parts can overlap one of its boxes (thr > 0)
                 unsigned long long todo = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);
-                if (cull) todo &= __ballot(u_valid && (bu_l.x <= tb.z) && (tb.x <= bu_l.z) && (bu_l.y <= tb.w) && (tb.y <= bu_l.w));
+                if (cull) todo &= __ballot(u_valid && (rects_meet(bu_l, tba) || rects_meet(bu_l, tbb)));
                 while (todo) {
                     const int k = __builtin_ctzll(todo);
                     todo &= todo - 1;
@@ -324,6 +357,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
         im.cur = reinterpret_cast<float4*>(w);                 w += c * sizeof(float4);
         im.nxt = reinterpret_cast<float4*>(w);                 w += c * sizeof(float4);
         im.bounds = reinterpret_cast<float4*>(w);              w += ((c + 63) / 64) * sizeof(float4);
+        im.bounds2 = reinterpret_cast<float4*>(w);             w += 2 * ((c + 63) / 64) * sizeof(float4);
         im.key = reinterpret_cast<unsigned*>(w);               w += c * sizeof(unsigned);
         im.flags = reinterpret_cast<unsigned*>(w);             w += c * sizeof(unsigned);
         im.act = reinterpret_cast<int*>(w);                    w += c * sizeof(int);
@@ -540,7 +574,7 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
 
 size_t ws_bytes_per_image(int cap) {
     const size_t c = (size_t)cap;
-    size_t bytes = 64 + 2 * c * sizeof(float4) + ((c + 63) / 64) * sizeof(float4) + 7 * c * sizeof(int);
+    size_t bytes = 64 + 2 * c * sizeof(float4) + 3 * ((c + 63) / 64) * sizeof(float4) + 7 * c * sizeof(int);
     return (bytes + 255) & ~(size_t)255;
 }
 

@@ -37,8 +37,7 @@ for b in range(2):
             x &= (s_ - 1); y &= (s_ - 1)     # keep the low bits
             s_ >>= 1
         return d
-    for name, cell in (('row-major', iy * 64 + ix), ('morton', part1by1(ix) | (part1by1(iy) << 1)), ('hilbert', hilbert(ix, iy)),
-                       ('2-row bands', (iy // 2) * 128 + ix * 2 + (iy & 1)), ('4-row bands', (iy // 4) * 256 + ix * 4 + (iy & 3))):
+    for name, cell in (('row-major', iy * 64 + ix), ('hilbert', hilbert(ix, iy))):
         order = np.argsort(cell, kind='stable')
         s = bx[order]
         nt = (n + 63) // 64
@@ -54,6 +53,33 @@ for b in range(2):
                 u = s[S*64:(S+1)*64]
                 k += ((u[:, 0] <= tb[2]) & (tb[0] <= u[:, 2]) & (u[:, 1] <= tb[3]) & (tb[1] <= u[:, 3])).sum()
             boxes_hit.append(k)
+        # the two parts of a tile: cut before the entry with the largest jump of the centre from its predecessor
+        parts = []
+        for t in range(nt):
+            tb_ = s[t*64:(t+1)*64]
+            c = np.stack([tb_[:, 0] + tb_[:, 2], tb_[:, 1] + tb_[:, 3]], 1)
+            j = np.abs(np.diff(c, axis=0)).sum(1)
+            cut = (int(np.argmax(j)) + 1) if len(j) and j.max() > 0 else min(32, len(tb_))
+            pa, pb = tb_[:cut], tb_[cut:]
+            ra = [pa[:, 0].min(), pa[:, 1].min(), pa[:, 2].max(), pa[:, 3].max()]
+            rb = [pb[:, 0].min(), pb[:, 1].min(), pb[:, 2].max(), pb[:, 3].max()] if len(pb) else [np.inf, np.inf, -np.inf, -np.inf]
+            parts.append((ra, rb))
+        def meet(u, r):
+            return (u[:, 0] <= r[2]) & (r[0] <= u[:, 2]) & (u[:, 1] <= r[3]) & (r[1] <= u[:, 3])
+        part_hit, pair_hit = [], []
+        for t in range(nt):
+            ra, rb = parts[t]
+            m = meet(s, ra) | meet(s, rb)
+            part_hit.append(m.sum())
+            # boxes with a real overlap with some box of the tile
+            tb_ = s[t*64:(t+1)*64]
+            u = s[m]
+            iw = np.minimum(u[:, None, 2], tb_[None, :, 2]) - np.maximum(u[:, None, 0], tb_[None, :, 0])
+            ih = np.minimum(u[:, None, 3], tb_[None, :, 3]) - np.maximum(u[:, None, 1], tb_[None, :, 1])
+            pair_hit.append(((iw > 0) & (ih > 0)).any(1).sum())
+        part_hit, pair_hit = np.array(part_hit), np.array(pair_hit)
+        print('   boxes meeting one of the two parts: mean %.0f median %.0f max %d; boxes overlapping a box of the tile: mean %.0f max %d' % (
+            part_hit.mean(), np.median(part_hit), part_hit.max(), pair_hit.mean(), pair_hit.max()))
         tiles_hit, boxes_hit = np.array(tiles_hit), np.array(boxes_hit)
         print(name, 'tiles', nt, 'candidate tiles per target: mean %.1f max %d; boxes inside the target bounds: mean %.0f median %.0f max %d' % (
             tiles_hit.mean(), tiles_hit.max(), boxes_hit.mean(), np.median(boxes_hit), boxes_hit.max()))
