@@ -150,11 +150,11 @@ class OcrPipeline:
         self.ctx.check_errors(synchronize=False)        # a timed-out recurrence fails the batch instead of returning garbage
         tokens, scores = st['h_tokens'].numpy(), st['h_scores'].numpy()
         box_img, box_idx = st['box_img'], st['box_idx']
-        decode = self.tokenizer.decode
-        for k in range(st['n']):
-            o, i = out[int(box_img[k])], int(box_idx[k])
-            o['texts'][i] = decode(tokens[k])
-            o['scores'][i] = float(scores[k])
+        texts = self.tokenizer.decode_batch(tokens[:st['n']])
+        for k, (b, i, text, score) in enumerate(zip(box_img.tolist(), box_idx.tolist(), texts, scores[:st['n']].tolist())):
+            o = out[b]
+            o['texts'][i] = text
+            o['scores'][i] = score
             o['valid'][i] = True
         return out
 

@@ -59,4 +59,42 @@ class CharTokenizer:
         return ''.join(out)
 
     def decode_batch(self, tokens):
-        return [self.decode(row) for row in tokens]
+        """Rows of token ids (n, T) -> list of n str, the same strings as `decode` row by row.  Vectorised over the
+        batch: a page batch of the pipeline has thousands of rows, and the per-row Python loop over all T positions
+        costs more host time than the GPU needs for the batch."""
+        import numpy as np
+        tokens = np.asarray(tokens)
+        if tokens.ndim != 2 or tokens.shape[0] == 0:
+            return [self.decode(row) for row in tokens]
+        n, T = tokens.shape
+        blank = self.blank_token_idx
+        # position of the first blank that is followed by a blank: decoding stops there
+        is_blank = tokens == blank
+        cut = np.full(n, T, dtype=np.int64)
+        if T > 1:
+            stop = is_blank[:, :-1] & is_blank[:, 1:]
+            cut = np.where(stop.any(axis=1), stop.argmax(axis=1), T)
+        table = self._table()
+        keep = ~is_blank & (np.arange(T)[None, :] < cut[:, None]) & (tokens >= 0) & (tokens < len(table))
+        counts = keep.sum(axis=1)
+        picked = tokens[keep]                              # row-major: row after row, positions ascending
+        ends = np.cumsum(counts)
+        if self._single_chars:
+            text = ''.join(table[picked].tolist())
+            starts = ends - counts
+            return [text[a:b] for a, b in zip(starts.tolist(), ends.tolist())]
+        symbols = table[picked].tolist()
+        return [''.join(symbols[a:b]) for a, b in zip((ends - counts).tolist(), ends.tolist())]
+
+    def _table(self):
+        """Symbols by id as a NumPy array ('' for ids without a symbol), built on first use."""
+        if getattr(self, '_table_cache', None) is None:
+            import numpy as np
+            size = max(self._id_to_symbol) + 1
+            table = np.array([self._id_to_symbol.get(i, '') for i in range(size)], dtype=object)
+            self._single_chars = all(len(sym) == 1 for i, sym in self._id_to_symbol.items() if i != self.blank_token_idx)
+            if self._single_chars:
+                table[self.blank_token_idx] = ' '          # never picked: blanks are dropped before the lookup
+                table = table.astype('<U1')
+            self._table_cache = table
+        return self._table_cache

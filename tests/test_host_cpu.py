@@ -65,6 +65,20 @@ def test_tokenizer_follows_reference_rules():
     assert tok.decode([-1, -1]) == ''
 
 
+def test_batch_decoding_equals_row_by_row_decoding():
+    from ocr_amd.utils.text import CharTokenizer, get_characters
+    rng = np.random.default_rng(3)
+    for chars in (None, get_characters('zh_sim_g2'), 'abca'):
+        tok = CharTokenizer(chars) if chars else CharTokenizer()
+        V = tok.vocab_size
+        rows = rng.integers(-2, V + 3, (300, 40)).astype(np.int32)          # ids without a symbol decode to nothing
+        rows[rng.random(rows.shape) < 0.3] = tok.blank_token_idx            # single and double blanks (a double one ends the text)
+        rows[::3, 12:] = -1                                                 # the padding of the CTC kernel
+        assert tok.decode_batch(rows) == [tok.decode(r) for r in rows]
+        assert tok.decode_batch(rows[:, :1]) == [tok.decode(r) for r in rows[:, :1]]
+        assert tok.decode_batch(np.zeros((0, 7), np.int32)) == []
+
+
 def test_registries_raise_like_the_reference():
     from ocr_amd.models import get_pretrained
     from ocr_amd.runtimes import build_runtime
