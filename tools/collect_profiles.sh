@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the profile set of one round on the GPU box (run from the repository root through gpurun):
-#   kernel trace + stats of the default bench command, then three counter passes of a short bench run.
+#   kernel trace + stats of the default bench command, then four counter passes of a short bench run.
 # Outputs land under gpurun_out/prof/; tools/pmc_traffic.py, pmc_mfma.py, pmc_summary.py and profile_report.py
 # turn them into the files kept under profiles/.
 set -e
@@ -15,4 +15,6 @@ timeout -s KILL 200 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write
 echo "write done"
 timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o m -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/mfma.log 2>&1
 echo "mfma done"
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/issue -o i -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/issue.log 2>&1
+echo "issue done"
 find $OUT -name "*.csv" | head -30

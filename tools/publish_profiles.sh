@@ -11,4 +11,5 @@ python tools/pmc_traffic.py $P/fetch $P/write > profiles/pmc_traffic.json
 python tools/pmc_summary.py $P/fetch > profiles/$R/pmc_fetch_size.csv
 python tools/pmc_summary.py $P/write > profiles/$R/pmc_write_size.csv
 python tools/pmc_mfma.py $P/mfma > profiles/$R/pmc_mfma_util.csv
+if [ -d $P/issue ]; then python tools/pmc_issue.py $P/issue > profiles/$R/pmc_issue.csv; fi
 python tools/profile_report.py profiles/$R > profiles/$R/kernel_report.md
