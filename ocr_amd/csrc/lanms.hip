@@ -129,15 +129,22 @@ __device__ void build_bounds(const Image& im, const float4* boxes, const int* ac
 // MODE 1: merge pass B   (writes nxt, kSupp; sets *cond)
 // MODE 2: NMS pass A     (writes kHasUpper among alive boxes)
 // MODE 3: NMS pass B     (writes kKill; sets *cond)
-template <int MODE>
+// NSUB = 1: a wave owns a target tile (tiles tile0 + wave, + tile_stride, ...).  NSUB = 4 (MODE 0, and MODE 1 with the
+// union merge; a workgroup of exactly 4 waves): the workgroup owns a target tile (tiles tile0, + tile_stride, ...) and
+// wave w compares it with the candidate tiles S = w (mod 4); the four partial results - flag bits, minima and maxima,
+// all independent of the order - are combined through `parts` (3 x 64 x 5 words of LDS).  A target tile's time is the
+// number of candidate boxes inside its bounds, 200 on average and up to 1400: with a tile per wave a pass lasts as
+// long as its slowest wave, 4.5x the average.
+template <int MODE, int NSUB = 1>
 __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr, bool cull, int merge_method,
-                           int* cond, int tile0 = 0, int tile_stride = kWaves) {
+                           int* cond, int tile0 = 0, int tile_stride = kWaves, float* parts = nullptr) {
+    static_assert(NSUB == 1 || (NSUB == 4 && MODE <= 1), "only the merge passes are split");
     n_act = __builtin_amdgcn_readfirstlane(n_act);       // wave-uniform by construction
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ntiles = (n_act + 63) >> 6;
     const float4* boxes = im.cur;
 
-    for (int T = tile0 + wave; T < ntiles; T += tile_stride) {
+    for (int T = tile0 + (NSUB == 1 ? wave : 0); T < ntiles; T += tile_stride) {
         const int e = T * 64 + lane;
         const bool t_valid = e < n_act;
         const int t = t_valid ? act[e] : 0;
@@ -170,6 +177,7 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
                     }
                 }
                 cand = __ballot(c);
+                if (NSUB > 1) cand &= 0x1111111111111111ull << wave;      // S0 is a multiple of 64: bit i is tile S0 + i
             }
             while (cand) {
                 const int S = S0 + __builtin_ctzll(cand);
@@ -232,6 +240,27 @@ __device__ void scan_pairs(const Image& im, const int* act, int n_act, float thr
             }
         }
 
+        if (NSUB > 1) {
+            // waves 1..3 hand their partial results to wave 0 (every wave of the workgroup walks the same tiles, so
+            // the barriers match)
+            if (wave > 0) {
+                float* q = parts + ((wave - 1) * 64 + lane) * 5;
+                q[0] = __uint_as_float((has_upper ? 1u : 0u) | (has_lower ? 2u : 0u) | (hit_by_clean ? 4u : 0u));
+                q[1] = mnx; q[2] = mny; q[3] = mxx; q[4] = mxy;
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w = 0; w < NSUB - 1; ++w) {
+                    const float* q = parts + (w * 64 + lane) * 5;
+                    const unsigned bits = __float_as_uint(q[0]);
+                    has_upper |= (bits & 1u) != 0; has_lower |= (bits & 2u) != 0; hit_by_clean |= (bits & 4u) != 0;
+                    mnx = fminf(mnx, q[1]); mny = fminf(mny, q[2]); mxx = fmaxf(mxx, q[3]); mxy = fmaxf(mxy, q[4]);
+                }
+            }
+            __syncthreads();
+            if (wave > 0) continue;
+        }
         if (!t_valid) continue;
         if (MODE == 0) {
             im.flags[t] = (fl_t & ~(kHasUpper | kHasLower | kSupp)) | (has_upper ? kHasUpper : 0u) |
@@ -369,6 +398,14 @@ __global__ __launch_bounds__(kThreads) void lanms_kernel(Params p) {
 
     const bool cull_merge = p.merge_thr > 0.f;
     if (p.phase == 2 || p.phase == 3) {      // one pass of the first iteration, tiles strided over gridDim.y workgroups
+        if (blockDim.x == 256) {             // workgroups of 4 waves that share a target tile (union merge)
+            float* parts = reinterpret_cast<float*>(s_hist);
+            if (p.phase == 2)
+                scan_pairs<0, 4>(im, im.act, n, p.merge_thr, cull_merge, p.merge_method, im.hdr, blockIdx.y, gridDim.y, parts);
+            else
+                scan_pairs<1, 4>(im, im.act, n, p.merge_thr, cull_merge, p.merge_method, im.hdr, blockIdx.y, gridDim.y, parts);
+            return;
+        }
         const int tile0 = blockIdx.y * kWaves, stride = gridDim.y * kWaves;
         if (p.phase == 2)
             scan_pairs<0>(im, im.act, n, p.merge_thr, cull_merge, p.merge_method, im.hdr, tile0, stride);
@@ -615,10 +652,16 @@ int launch_lanms(ocrhip_ctx* h, const float* xyxy, const float* scores, const in
     } else {
         p.phase = 1;
         hipLaunchKernelGGL(lanms_kernel, dim3(B), dim3(kThreads), 0, s, p);
+        // the two passes over all candidates: with the union merge (order-independent accumulators) a workgroup of 4
+        // waves per target tile, as many workgroups as the images can have tiles (up to 512 per image; the hardware
+        // hands them to the CUs as others finish, which evens out the very different tile times); else 16 waves with a
+        // tile each
+        const bool shared_tiles = merge_method == OCRHIP_MERGE_UNION;
+        const dim3 pgrid(B, shared_tiles ? std::min(512, (cap + 63) / 64) : G), pblock(shared_tiles ? 256 : kThreads);
         p.phase = 2;
-        hipLaunchKernelGGL(lanms_kernel, dim3(B, G), dim3(kThreads), 0, s, p);
+        hipLaunchKernelGGL(lanms_kernel, pgrid, pblock, 0, s, p);
         p.phase = 3;
-        hipLaunchKernelGGL(lanms_kernel, dim3(B, G), dim3(kThreads), 0, s, p);
+        hipLaunchKernelGGL(lanms_kernel, pgrid, pblock, 0, s, p);
         p.phase = 4;
         hipLaunchKernelGGL(lanms_kernel, dim3(B), dim3(kThreads), 0, s, p);
     }
