@@ -222,6 +222,23 @@ def test_lanms_decoded_pages_match_c_oracle(ctx):
         assert 20 <= int(got['counts'][b]) <= 200      # roughly one box per rendered word
 
 
+@pytest.mark.parametrize('method', ['average', 'weighted'])
+def test_lanms_order_dependent_merges_on_a_decoded_page(ctx, method):
+    """The first iteration over thousands of candidates runs as separate launches; the merges that sum in list order
+    ('average', and the 'weighted' extension) keep a target tile per wave there (the union merge shares a tile between
+    waves).  One decoded 512x512 page against the NumPy oracle."""
+    from ocr_amd import synth
+    _, maps, _ = synth.make_pages(23, 1, 512, 512, 60)
+    dec = ctx.east_decode(_dev(maps), (512, 512), 0.35)
+    kw = dict(merge_threshold=0.3, nms_threshold=0.2, merge_method=method)
+    out = ctx.lanms(dec['xyxy'], dec['scores'], dec['counts'], full=True, **kw)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    n = int(dec['counts'].cpu().numpy()[0])
+    assert n > 1000
+    _compare_with_oracle(got, 0, dec['xyxy'].cpu().numpy()[0, :n], dec['scores'].cpu().numpy()[0, :n], onms.lanms, exact=False, **kw)
+
+
 def test_lanms_rejects_non_positive_threshold(ctx):
     with pytest.raises(ValueError):
         _gpu_lanms(ctx, [CHAIN], None, merge_threshold=0.0, nms_threshold=0.2)
