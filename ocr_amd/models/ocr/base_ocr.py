@@ -144,8 +144,9 @@ class BaseOCR:
                 padded[k, :T[k]] = flat[row0[k]:row0[k + 1]]
             toks, sc = ctc_beam_search(padded, T, num_beams=num_beams, blank=self.blank_token_idx)
         texts, scores = [None] * n, np.zeros(n, np.float32)
+        decoded = self.tokenizer.decode_batch(np.asarray(toks)[:n])
         for k, j in enumerate(order):
-            texts[j] = self.tokenizer.decode(toks[k])
+            texts[j] = decoded[k]
             scores[j] = sc[k]
         return list(plan['index']), texts, scores
 
