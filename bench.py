@@ -49,7 +49,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='pages per step and per GPU')
+    ap.add_argument('--batch', type=int, default=48, help='pages per step and per GPU (25 GB of activations in flight per 48 pages)')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--words', type=int, default=220)
     ap.add_argument('--vocab', type=int, default=97, help='classes of the recogniser head (97 = english_g2, 6719 = zh_sim_g2)')

@@ -9,12 +9,12 @@ OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py > $OUT/bench_default.json.log 2> $OUT/trace.err
 echo "trace done"
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/fetch.log 2>&1
+timeout -s KILL 280 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $OUT/fetch.log 2>&1
 echo "fetch done"
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o w -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/write.log 2>&1
+timeout -s KILL 280 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o w -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $OUT/write.log 2>&1
 echo "write done"
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o m -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/mfma.log 2>&1
+timeout -s KILL 280 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o m -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $OUT/mfma.log 2>&1
 echo "mfma done"
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/issue -o i -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/issue.log 2>&1
+timeout -s KILL 280 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/issue -o i -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $OUT/issue.log 2>&1
 echo "issue done"
 find $OUT -name "*.csv" | head -30

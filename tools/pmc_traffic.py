@@ -62,7 +62,7 @@ def main(fetch_dir, write_dir):
         fetch, write = f[k][1] / n * 1024.0, w[k][1] / n * 1024.0
         out[k] = {'launches': n, 'fetch_size_bytes_per_launch': fetch, 'write_size_bytes_per_launch': write,
                   'traffic_bytes_per_launch': 2.0 * fetch + write}
-    json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1',
+    json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1',
                'correction': 'traffic = 2 x FETCH_SIZE + WRITE_SIZE', 'kernels': out}, sys.stdout, indent=1)
 
 
