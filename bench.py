@@ -319,7 +319,9 @@ def main():
             'gpu_time': {'source': 'every launch timed in an untimed pass of %d steps behind the timed region (in the timed '
                                    'region only the dominant kernel carries events)' % breakdown_steps,
                          'kernels_ms_per_step': gpu_ms / breakdown_steps, 'all_mfma_conv_tflops_direct_equiv': conv_tflops,
-                         'stages_ms_per_step': {s['name']: round(s['total_ms'] / breakdown_steps, 3) for s in stats}},
+                         'stages_ms_per_step': {s['name']: round(s['total_ms'] / breakdown_steps, 3) for s in stats},
+                         'stages_tflops_direct_equiv': {s['name']: round(s['flops'] / (s['total_ms'] * 1e-3) / 1e12, 1)
+                                                        for s in stats if s['flops'] > 0 and s['total_ms'] > 0}},
         }
         if world == 1 and not args.no_cpu_baseline and args.vocab == 97 and not args.rotated:
             line['cpu_baseline'] = cpu_baseline(images, maps, east_params, crnn_params, min(args.cpu_pages, B))
