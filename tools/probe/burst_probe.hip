@@ -6,6 +6,8 @@
 //   pattern 0: the F(4x4) kernel's order: a load covers 16 channels (2 lanes per pixel and 8 channels), so a 128-byte
 //              line is touched by four different loads
 //   pattern 1: 8 consecutive lanes cover the 128 bytes of a pixel: every line is requested once
+//   pattern 2: pattern 0 right behind the stores of an output tile (8 x 32 pixels x 128 channels, 128 KB per workgroup),
+//              as at the end of one tile and the start of the next
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/probe/burst_probe tools/probe/burst_probe.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -15,7 +17,7 @@
 constexpr int kW = 512, kH = 512, kRawW = 34, kRawH = 10, kPx = kRawW * kRawH;
 
 template <int PATTERN>
-__global__ __launch_bounds__(512, 1) void burst(const float* x, int C, int tiles_x, int tile0, long long* cycles, float* sink) {
+__global__ __launch_bounds__(512, 1) void burst(const float* x, int C, int tiles_x, int tile0, long long* cycles, float* sink, float* y) {
     const int tid = threadIdx.x;
     const int tile_all = tile0 + blockIdx.x;
     const int per_image = tiles_x * (kH / 8);
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(512, 1) void burst(const float* x, int C, int tiles
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         int px, byte;
-        if (PATTERN == 0) {
+        if (PATTERN == 0 || PATTERN == 2) {
             // loads 0..2: channels 0..15 (sub-chunk i: 8 channels, lanes (pixel, quad)); loads 3..5: channels 16..31
             const int chunk = i / 3, j = i % 3;
             const int sub = j == 2 ? (tid >> 8) : j;
@@ -42,6 +44,14 @@ __global__ __launch_bounds__(512, 1) void burst(const float* x, int C, int tiles
         const int gy = y0 - 1 + px / kRawW, gx = x0 - 1 + px % kRawW;
         const bool ok = px >= 0 && px < kPx && gy >= 0 && gy < kH && gx >= 0 && gx < kW;
         off[i] = ok ? ((gy * kW + gx) * C * 4 + byte) : (int)0x80000000;
+    }
+    if (PATTERN == 2) {          // the output tile of the workgroup before: 256 pixels x 512 bytes, 16 stores of 16 bytes per thread
+        float* yt = y + ((int64_t)(b * kH + y0) * kW + x0) * 128;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int px = it * 16 + (tid >> 5), row = px >> 5, col = px & 31;
+            *reinterpret_cast<float4*>(yt + ((int64_t)row * kW + col) * 128 + (tid & 31) * 4) = float4{1.f, 2.f, 3.f, (float)tid};
+        }
     }
     __syncthreads();
     const long long t0 = __builtin_readcyclecounter();
@@ -68,14 +78,17 @@ int main() {
     float* x;
     long long* d_cycles;
     float* sink;
+    float* y;
+    if (hipMalloc(&y, floats * 2 * 4) != hipSuccess) return 1;
     if (hipMalloc(&x, floats * 4) != hipSuccess || hipMalloc(&d_cycles, 2 * 4096 * sizeof(long long)) != hipSuccess || hipMalloc(&sink, 16) != hipSuccess) return 1;
     hipMemset(x, 0, floats * 4);
     int tile0 = 0;
-    for (int pattern = 0; pattern < 2; ++pattern)
+    for (int pattern = 0; pattern < 3; ++pattern)
         for (int wgs : {8, 32, 64, 128, 256}) {
             for (int rep = 0; rep < 2; ++rep) {
-                if (pattern == 0) hipLaunchKernelGGL(burst<0>, dim3(wgs), dim3(512), 0, 0, x, C, tiles_x, tile0, d_cycles, sink);
-                else hipLaunchKernelGGL(burst<1>, dim3(wgs), dim3(512), 0, 0, x, C, tiles_x, tile0, d_cycles, sink);
+                if (pattern == 0) hipLaunchKernelGGL(burst<0>, dim3(wgs), dim3(512), 0, 0, x, C, tiles_x, tile0, d_cycles, sink, y);
+                else if (pattern == 1) hipLaunchKernelGGL(burst<1>, dim3(wgs), dim3(512), 0, 0, x, C, tiles_x, tile0, d_cycles, sink, y);
+                else hipLaunchKernelGGL(burst<2>, dim3(wgs), dim3(512), 0, 0, x, C, tiles_x, tile0, d_cycles, sink, y);
                 if (hipDeviceSynchronize() != hipSuccess) return 2;
                 std::vector<long long> c(2 * wgs);
                 hipMemcpy(c.data(), d_cycles, 2 * wgs * sizeof(long long), hipMemcpyDeviceToHost);
