@@ -64,9 +64,13 @@ void set_current_profiler(Profiler* p);
 // without a scalar offset register; the s_nop takes the data as an operand, so nothing can be scheduled between the two
 // that writes them.  (Stores of 8 bytes or less are not affected.)
 typedef float ocr_floatx4 __attribute__((ext_vector_type(4)));
+// AUX: cache policy bits of the store; kStreamingStore marks data that the kernel does not read again (a layer's
+// output): those lines are the first to leave the L2, which keeps the filters and the neighbours' halo pixels there.
+constexpr int kStreamingStore = 2;          // nt
+template <int AUX = 0>
 __device__ __forceinline__ void buffer_store_b128_guarded(ocr_floatx4 data, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, data), rsrc,
-                                           voffset, soffset, 0);
+                                           voffset, soffset, AUX);
     asm volatile("s_nop 1" ::"v"(data));
 }
 #endif

@@ -627,7 +627,7 @@ __global__ __launch_bounds__(MODE == 3 ? 256 : 512, MODE == 3 ? 2 : 1) void conv
                 if (a.relu) {
                     val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
                 }
-                buffer_store_b128_guarded(val, y_rsrc, voff, soff);
+                buffer_store_b128_guarded<kStreamingStore>(val, y_rsrc, voff, soff);
             }
             return;
         }
