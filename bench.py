@@ -5,9 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the whole hot path over a batch of pages already resident in HBM:
-EAST-VGG16 forward (f32 MFMA) -> RBOX decode -> LANMS + NMS -> crop/resize/pack -> CRNN + CTC greedy
--> strings on the host.  Images are independent, so ranks share no data (weak scaling: N x steps
+One "step" = one pass of the whole hot path over a batch of pages: host -> device copy of the uint8 pages
+(pinned memory, a copy stream of its own, one batch ahead of the compute stream; `--resident` re-feeds a
+batch that already sits in HBM instead) -> EAST-VGG16 forward (f32 MFMA) -> RBOX decode -> LANMS + NMS
+-> crop/resize/pack -> CRNN + CTC greedy -> strings on the host.  Images are independent, so ranks share no data (weak scaling: N x steps
 batches per job, no collective in the data path).  The batches of the timed region sit in ONE queue
 all ranks take from (post-NMS word counts differ, a rank that is done early takes more), and every
 rank's boxes + strings are gathered on the host of rank 0 before the clock stops; one barrier and
@@ -58,6 +59,8 @@ def parse():
     ap.add_argument('--rotated', action='store_true',
                     help='opt-in path that keeps the quadrilaterals: rotated-IoU NMS + rotated crops (not the '
                          'reference behaviour; the CPU baseline is skipped)')
+    ap.add_argument('--resident', action='store_true',
+                    help='pages already in HBM when the clock starts (no host -> device copy inside the timed region)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-pages', type=int, default=4)
     ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE',
@@ -210,23 +213,72 @@ def main():
     images, maps, _ = synth.make_pages(1234 + 4 + 100 * rank, B, S, S, args.words)
     d_img = torch.from_numpy(images).cuda()
     d_maps = torch.from_numpy(maps).cuda()
+    # Host -> device inside the clock: the pages of every batch are copied from pinned host memory on a copy stream, one
+    # batch ahead of the compute stream, into a ring of three device buffers (a batch's pages are read by its detector
+    # and, one pipeline turn later, by its crop kernel; the buffer is written again two turns after that).
+    h_img = torch.from_numpy(images).pin_memory()
+    ring = [d_img] + [torch.empty_like(d_img) for _ in range(2)] if not args.resident else [d_img]
+    copy_stream = torch.cuda.Stream()
+    copied = {}
 
-    def run(batch_ids):
+    def upload(k):
+        """Enqueues the copy of batch number k of a run into ring slot k % 3, behind everything the compute stream
+        holds so far (the last reader of that slot is among it)."""
+        free = torch.cuda.Event()
+        free.record()
+        copy_stream.wait_event(free)
+        with torch.cuda.stream(copy_stream):
+            ring[k % 3].copy_(h_img, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        copied[k] = ev
+
+    retried = []
+
+    def run(batch_ids, queue=None):
         """Streams the batches named by `batch_ids` through the pipeline (detection of batch i+1 is enqueued while
         the host prepares the crops of batch i); every batch is complete, strings on the host, when it is yielded.
+        With a `queue`, finished batches are reported to it and the batches in flight when a GPU call raises go back
+        to it for another rank (this rank drains its stream and carries on with what the queue hands it next).
         -> [(batch id, {'counts', 'boxes', 'texts'})]"""
-        ids, results = [], []
+        from ocr_amd._lib import OcrHipError
+        results = []
+        ids = iter(batch_ids)
+        while True:
+            inflight = []
 
-        def feed():
-            for i in batch_ids:
-                ids.append(i)
-                yield d_img, d_maps
-        for k, out in enumerate(pipe.run_batches(feed())):
-            results.append((ids[k], {
-                'counts': [len(o['boxes']) for o in out],
-                'boxes': np.concatenate([o['boxes'] for o in out]) if out else np.zeros((0, 4), np.float32),
-                'texts': [t for o in out for t, v in zip(o['texts'], o['valid']) if v]}))
-        return results
+            def feed():
+                k = 0
+                if not args.resident:
+                    copied.clear()
+                    upload(0)
+                for i in ids:
+                    inflight.append(i)
+                    if args.resident:
+                        yield d_img, d_maps
+                    else:
+                        torch.cuda.current_stream().wait_event(copied.pop(k))
+                        upload(k + 1)
+                        yield ring[k % 3], d_maps
+                    k += 1
+            try:
+                for out in pipe.run_batches(feed()):
+                    i = inflight.pop(0)
+                    results.append((i, {
+                        'counts': [len(o['boxes']) for o in out],
+                        'boxes': np.concatenate([o['boxes'] for o in out]) if out else np.zeros((0, 4), np.float32),
+                        'texts': [t for o in out for t, v in zip(o['texts'], o['valid']) if v]}))
+                    if queue is not None:
+                        queue.done(i)
+                return results
+            except OcrHipError as e:
+                if queue is None:
+                    raise
+                sys.stderr.write('bench.py: rank %d: %s; %d batch(es) go back to the queue\n' % (rank, e, len(inflight)))
+                torch.cuda.synchronize()
+                for i in inflight:
+                    retried.append(i)
+                    queue.give_back(i)
 
     def sync():
         torch.cuda.synchronize()
@@ -250,7 +302,7 @@ def main():
     pipe.ctx.profile_enable(True)
     sync()
     t0 = time.perf_counter()
-    local = run(queue)
+    local = run(iter(queue.take, None), queue)
     torch.cuda.synchronize()
     gathered = gather_results(local, n_batches, grp if dist is not None else None, dst=0)     # host gather, rank 0
     elapsed = time.perf_counter() - t0
@@ -297,7 +349,9 @@ def main():
                                         'runs and is timed',
                        'parallelism': 'image-sharded x%d, one shared batch queue, boxes + strings gathered on the host of '
                                       'rank 0 inside the timed region' % world,
-                       'batches_taken_by_rank0': len(local)},
+                       'input': 'uint8 pages resident in HBM' if args.resident else
+                                'pinned host uint8, H2D timed (copy stream, one batch ahead of the compute stream)',
+                       'batches_taken_by_rank0': len(local), 'batches_given_back_by_rank0': len(retried)},
             **({'rehearsal': '--share-gpu: all ranks on one GPU, not a scaling result'} if args.share_gpu else {}),
             **({'variant': '--rotated: rotated-IoU NMS + rotated crops, an opt-in extension, not the reference path'}
                if args.rotated else {}),

@@ -101,7 +101,9 @@ int ocrhip_destroy(ocrhip_handle h);
  *   results equal the image-by-image launch (0) to the algorithm's rounding error (~1e-5 of the output scale), not bit
  *   for bit, and depend on which images share a launch to that extent.
  *   "first_layer_mfma": 1 (default) runs the detector's first convolution (3 -> 64 channels) on the matrix cores, 0 on
- *   the vector ALU; both sum the 27 products of an output in the same order: identical results.
+ *   the vector ALU; the same 27 exact products per output, summed in pairs of taps by the matrix instruction
+ *   (v_mfma_f32_32x32x2_f32 adds two products per step) and one by one by the vector kernel: bit-identical on gfx950 as
+ *   pinned by the tests (random and large mixed-sign inputs), not by construction.
  *   "flat_gemm": 1 (default) runs the Dense layers, the LSTM input projections and the 2x2 convolutions as a flat
  *   GEMM with 256 x 128 tiles; 0 runs them on the implicit-GEMM convolution kernel (256 x 64 / spatial tiles).  Same
  *   arithmetic (a float32 fma chain over k in both).
@@ -303,12 +305,16 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
                                ocrhip_stream stream);
 
 /* Asynchronous failures of earlier calls on the handle.  The persistent BiLSTM kernel cannot return a code when a
- * hand-over between its workgroups times out; it sets a sticky device word that every ocrhip_crnn_forward* call copies
- * to the host behind its results.  This call reports it: OCRHIP_EHIP with "lstm hand-over timed out" once, then the
- * word is re-armed; OCRHIP_OK otherwise.  synchronize != 0 waits for `stream` first (so the outputs of every call
- * enqueued so far are covered); with 0 the caller has already waited (event / stream synchronisation) for the outputs
- * it is about to use.  ocrhip_crnn_forward* perform the same check on entry.  The reference has no counterpart: its
- * Keras LSTM raises synchronously. */
+ * hand-over between its workgroups times out; it sets a device word that is cleared, in stream order, at the start of
+ * every ocrhip_crnn_forward* call (a time-out of one call never makes a later call's kernels leave early) and copied
+ * to the host behind that call's results, into a status slot of the call's own (a ring of 16; the 17th call in flight
+ * waits for the first).  This call reads the slots that have arrived, in call order: OCRHIP_OK when none carries an
+ * error.  On an error it waits for `stream`, returns OCRHIP_EHIP with "lstm hand-over timed out" once, and EVERY
+ * recogniser call enqueued on the handle before this check counts as failed (one return code cannot say which of
+ * several pipelined calls it was): run them again.  synchronize != 0 waits for `stream` first (so every call enqueued
+ * so far is covered); with 0 the caller has already waited (event / stream synchronisation) for the outputs it is
+ * about to use.  ocrhip_crnn_forward* perform the same check on entry.  The reference has no counterpart: its Keras
+ * LSTM raises synchronously. */
 int ocrhip_check_errors(ocrhip_handle h, ocrhip_stream stream, int synchronize);
 
 /* Debug / test access to an activation of the last ocrhip_crnn_forward call (synchronises).

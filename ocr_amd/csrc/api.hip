@@ -715,6 +715,8 @@ static int crnn_features(CrnnNet& net, const float* x, int n, int Wpad, float* f
     return OCRHIP_OK;
 }
 
+static int crnn_report_timeout(CrnnNet& net, hipStream_t s);
+
 // 2 x [BiLSTM(256) -> Dense(256)] -> Dense(vocab) over R = sum of T rows of `feats`.
 // Uniform mode: seq_T == nullptr, every sequence has Tmax steps.  Ragged mode: host_T (non-decreasing)
 // and the device arrays d_T / d_row0 describe the sequences.
@@ -732,9 +734,12 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
         OCR_HIP_CHECK(hipMemsetAsync(net.lstm_counters.ptr, 0, (kLstmCounterCount + kLstmErrorWords) * sizeof(unsigned), s));
     }
     if (!net.lstm_err_host) {
-        OCR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&net.lstm_err_host), sizeof(unsigned), hipHostMallocDefault));
-        *net.lstm_err_host = 0;
+        OCR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&net.lstm_err_host), CrnnNet::kErrSlots * sizeof(unsigned), hipHostMallocDefault));
+        for (int i = 0; i < CrnnNet::kErrSlots; ++i) net.lstm_err_host[i] = 0;
     }
+    // every forward starts from clean error words (in stream order: an earlier call's time-out cannot make this call's
+    // kernels leave early) and reports into a status slot of its own
+    OCR_HIP_CHECK(hipMemsetAsync(net.lstm_counters.as<unsigned>() + kLstmCounterCount, 0, kLstmErrorWords * sizeof(unsigned), s));
     const float* layer_in = feats;
     for (int l = 0; l < 2; ++l) {
         float* xw_f = net.xw.as<float>();
@@ -776,9 +781,15 @@ static int crnn_sequence(CrnnNet& net, const float* feats, int n, int64_t R, int
         OCR_TRY(net.pidx.reserve(pairs * sizeof(int)));
         OCR_TRY(launch_gemm_f32_argmax(net.pred, layer_in, R, net.pmax.as<float>(), net.pidx.as<int>(), s));
     }
-    // the sticky error word of the persistent recurrence travels to the host behind the results
-    OCR_HIP_CHECK(hipMemcpyAsync(net.lstm_err_host, net.lstm_counters.as<unsigned>() + kLstmCounterCount, sizeof(unsigned),
-                                 hipMemcpyDeviceToHost, s));
+    // the error word of this call's recurrences travels to the host behind the results, into the call's own slot
+    if (net.calls_started - net.calls_checked >= (uint64_t)CrnnNet::kErrSlots) {      // ring full: wait for the calls in flight
+        OCR_HIP_CHECK(hipStreamSynchronize(s));
+        OCR_TRY(crnn_report_timeout(net, s));
+    }
+    unsigned* slot = net.lstm_err_host + net.calls_started % CrnnNet::kErrSlots;
+    *slot = CrnnNet::kErrPending;
+    OCR_HIP_CHECK(hipMemcpyAsync(slot, net.lstm_counters.as<unsigned>() + kLstmCounterCount, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    ++net.calls_started;
     return OCRHIP_OK;
 }
 
@@ -789,13 +800,25 @@ static bool crnn_can_fuse_ctc(const CrnnNet& net) {
 }
 
 // A persistent recurrence of an earlier call on this handle gave up waiting for its partner workgroups: that call's
-// outputs are incomplete.  Reports it once (and re-arms the error word behind the work already on the stream).
+// outputs are incomplete.  Every forward has a status slot of its own (pinned, written behind its results); the slots
+// of the calls whose status has arrived are read in call order.  On an error the stream is drained and EVERY forward
+// enqueued before this check counts as failed (the caller cannot tell from one return code which of its pipelined
+// calls it was), reported once.
 static int crnn_report_timeout(CrnnNet& net, hipStream_t s) {
-    if (!net.lstm_err_host || *net.lstm_err_host == 0) return OCRHIP_OK;
-    *net.lstm_err_host = 0;
-    OCR_HIP_CHECK(hipMemsetAsync(net.lstm_counters.as<unsigned>() + kLstmCounterCount, 0, kLstmErrorWords * sizeof(unsigned), s));
+    if (!net.lstm_err_host) return OCRHIP_OK;
+    bool failed = false;
+    while (net.calls_checked < net.calls_started) {
+        const unsigned v = *reinterpret_cast<volatile unsigned*>(net.lstm_err_host + net.calls_checked % CrnnNet::kErrSlots);
+        if (v == CrnnNet::kErrPending) break;          // that call has not finished yet
+        if (v != 0) { failed = true; break; }
+        ++net.calls_checked;
+    }
+    if (!failed) return OCRHIP_OK;
+    OCR_HIP_CHECK(hipStreamSynchronize(s));
+    net.calls_checked = net.calls_started;
     set_error("lstm hand-over timed out: a persistent BiLSTM launch did not have the whole GPU (another process or stream held "
-              "compute units); the recogniser outputs of that call are invalid.  Retry, or ocrhip_set_option(h, \"lstm_persistent\", 0)");
+              "compute units); the outputs of every recogniser call enqueued before this check are invalid.  Retry, or "
+              "ocrhip_set_option(h, \"lstm_persistent\", 0)");
     return OCRHIP_EHIP;
 }
 

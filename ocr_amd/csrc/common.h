@@ -157,7 +157,10 @@ struct CrnnNet {
     DevBuf act[3];
     DevBuf feats, xw, hbuf, cbuf, seq, lin, logits, meta, lstm_counters;
     DevBuf pmax, pidx;       // greedy decoding without logits: per row and block of 128 classes the maximum and its class
-    unsigned* lstm_err_host = nullptr;   // pinned: copy of the kernel's sticky error word, refreshed after every forward
+    static constexpr int kErrSlots = 16;
+    static constexpr unsigned kErrPending = 0xFFFFFFFFu;
+    unsigned* lstm_err_host = nullptr;   // pinned ring: the error word of forward number k lands in slot k % kErrSlots behind its results
+    uint64_t calls_started = 0, calls_checked = 0;   // forwards enqueued / forwards whose status slot has been read
     PinnedRing ring;
     std::map<std::string, Activation> taps;
 };
@@ -285,8 +288,8 @@ int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, c
                      const int* seq_row0, int first, int H, hipStream_t s);
 
 // rnn_persistent.hip: a whole bidirectional layer in one launch of persistent workgroups (hbuf: 2 parities x 2 directions x n x 256,
-// counters: kLstmCounterCount unsigned ints cleared per launch, followed by kLstmErrorWords sticky error words the kernel
-// sets when a hand-over between workgroups times out).  OCRHIP_ESTATE when the hidden size is not 256, the device cannot
+// counters: kLstmCounterCount unsigned ints cleared per launch, followed by kLstmErrorWords error words the kernel
+// sets when a hand-over between workgroups times out and the caller clears at the start of every forward).  OCRHIP_ESTATE when the hidden size is not 256, the device cannot
 // hold the grid at once or a workgroup would need more passes than it has counters (use the per-step kernel).
 constexpr int kLstmCounterCount = 2 * 16 * 64;
 constexpr int kLstmErrorWords = 16;

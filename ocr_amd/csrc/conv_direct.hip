@@ -311,8 +311,9 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const void* __rest
 // then sit in registers 4 q .. 4 q + 3 of ONE lane (accumulator register v of a lane holds row (v & 3) + 8 (v >> 2) +
 // 4 (lane >> 5)), so the pooling is three v_max in registers, and for a fixed q the lanes of a wave hold 2 pixels x 32
 // consecutive channels = 256 contiguous bytes of the NHWC output: plain coalesced stores, no transpose.  A workgroup
-// owns 8 pooled rows x 64 pooled columns of one image: its 18 x 130 input values go through LDS once.  Same products in
-// the same order as conv_first_kernel, max and bias + ReLU in the same order: identical results.
+// owns 8 pooled rows x 64 pooled columns of one image: its 18 x 130 input values go through LDS once.  Same products,
+// taps summed in the order of conv_first_kernel (the matrix instruction adds two per step), max and bias + ReLU in the
+// same order: bit-identical on gfx950, which the tests pin; the instruction's internal order does not guarantee it.
 __global__ __launch_bounds__(256) void conv_first_pool_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                    const float* __restrict__ bias, float* __restrict__ y,
                                                                    int H, int W) {

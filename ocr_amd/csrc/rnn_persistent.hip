@@ -23,7 +23,7 @@
 // Nothing else synchronises; a group whose sequences are all finished leaves.  The grid never exceeds what the device
 // holds at once (occupancy x CUs, checked by the launcher: the hand-over needs every workgroup resident, and launches
 // of this kernel on one device are chained through an event so that two of them never share the device); the spin on
-// the counter is bounded so that a lost partner can never hang the device: a wait that gives up sets a sticky error
+// the counter is bounded so that a lost partner can never hang the device: a wait that gives up sets an error
 // word and the workgroup LEAVES (its partners see the word within 256 spins and leave too).  The layer's output is
 // then incomplete; the host reads the error word with the results and fails the call (ocrhip_check_errors).
 //
@@ -57,7 +57,7 @@ struct LayerArgs {
     const int* seq_row0;     // first row of each sequence in the flat matrices; nullptr: s * T
     const int* step_active;  // sequences with more than t steps, per step t; nullptr: n
     unsigned* counters;      // (2 directions x G, kMaxPass), zero at launch
-    unsigned* error;         // sticky: set to 1 by a workgroup whose wait for its partners timed out
+    unsigned* error;         // set to 1 by a workgroup whose wait for its partners timed out
     int n, T, G;
     int spin_cap;            // spins of a wait before it gives up
     int debug_drop;          // test hook: unit block 7 of (direction 0, group 0) never publishes step 0
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves_kernel(const LayerArg
 }  // namespace
 
 // One bidirectional LSTM layer over n sequences in one launch of persistent workgroups.  `counters` must hold
-// kLstmCounterCount + kLstmErrorWords unsigned ints (the counters are cleared here, the error words are sticky).
+// kLstmCounterCount + kLstmErrorWords unsigned ints (the counters are cleared here, the error words by the caller at the start of a forward).
 // Returns OCRHIP_ESTATE when the hidden size is not 256 or the device cannot hold the grid at once; the caller then
 // uses the per-step kernel.
 namespace {

@@ -29,10 +29,30 @@ class Group:
         return tuple(self) == tuple(other)
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        return s.getsockname()[1]
+_stores = []
+
+
+def _serve_store(addr, world, tries=16):
+    """Rank 0: opens the job's key-value store on a port the system picks and returns (store, port).  The port is the
+    one the server really listens on (binding port 0 inside the server: nothing can take it between a probe and the
+    listen); a torch without that feature gets a probed port and a few retries when somebody else was faster."""
+    import torch.distributed as dist
+    try:
+        store = dist.TCPStore(addr, 0, world, is_master=True, wait_for_workers=False)
+        if int(store.port) > 0:
+            return store, int(store.port)
+    except (RuntimeError, ValueError, TypeError):
+        pass
+    last = None
+    for _ in range(tries):
+        with socket.socket() as s:
+            s.bind((addr if addr not in ('localhost',) else '127.0.0.1', 0))
+            port = s.getsockname()[1]
+        try:
+            return dist.TCPStore(addr, port, world, is_master=True, wait_for_workers=False), port
+        except RuntimeError as e:                 # address in use: somebody took the port after the probe
+            last = e
+    raise RuntimeError('could not open a TCPStore on %s: %s' % (addr, last))
 
 
 def init_from_env(backend=None, device=None):
@@ -51,43 +71,133 @@ def init_from_env(backend=None, device=None):
     rank, world = dist.get_rank(), dist.get_world_size()
     # host-side collectives (python objects) never go through the GPUs
     host_group = dist.new_group(backend='gloo') if dist.get_backend() != 'gloo' else dist.group.WORLD
-    # a store of the job's own for the page queue: rank 0 serves it on a free port it tells the others
-    port = [_free_port() if rank == 0 else None]
-    dist.broadcast_object_list(port, src=0, group=host_group)
-    store = dist.TCPStore(os.environ.get('MASTER_ADDR', '127.0.0.1'), int(port[0]), world, is_master=(rank == 0),
-                          wait_for_workers=True)
+    # a store of the job's own for the page queues: rank 0 opens the server first and tells the others the port it
+    # listens on
+    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    store, port = _serve_store(addr, world) if rank == 0 else (None, None)
+    box = [port]
+    dist.broadcast_object_list(box, src=0, group=host_group)
+    if rank != 0:
+        store = dist.TCPStore(addr, int(box[0]), world, is_master=False)
+    _stores.append(store)                     # the server must outlive a caller that drops the Group
+    dist.barrier(group=host_group)            # every client is connected before anybody goes on
     return Group(rank, world, dist, host_group, store)
+
+
+class QueueAborted(RuntimeError):
+    """A work item failed on as many ranks as the job has: the queue gives up on every rank."""
 
 
 class PageQueue:
     """A shared queue of `n_items` work items (page batches) numbered 0..n_items-1: `take()` hands every item to
-    exactly one rank, in order, whichever rank asks first; None when the queue is empty.  One atomic add on the
-    job's store per item (~0.1 ms on loopback against ~70 ms of GPU work per batch of pages)."""
+    exactly one rank, in order, whichever rank asks first; None when every item is done.  One atomic add on the
+    job's store per item (~0.1 ms on loopback against ~150 ms of GPU work per batch of pages).
 
-    def __init__(self, n_items, group=None, key='pages'):
+    A rank that cannot finish an item (its GPU call raised) calls `give_back(i)`: the number goes to a list of
+    returned items in the store and another rank takes it; `done(i)` reports a finished item.  A rank whose first-come
+    items are used up keeps polling the returned list until all `n_items` are reported done, so a returned item
+    always finds a taker.  `for i in queue:` reports `done` for an item when the loop body comes back for the next
+    one without having given it back.  An item that fails on `max_attempts` ranks (default: every rank once, at
+    least 2) aborts the queue on all ranks (`QueueAborted`).
+
+    Every queue of a job has keys of its own in the store (a per-group sequence number, the same on all ranks as
+    long as they create their queues in the same order), so a second queue starts at zero."""
+
+    POLL_S = 0.005
+
+    def __init__(self, n_items, group=None, key=None, max_attempts=None):
         self.n_items = int(n_items)
         self.store = group.store if group is not None else None
+        self.rank = group.rank if group is not None else 0
+        world = group.world if group is not None else 1
+        if key is None:
+            seq = getattr(group, '_queue_seq', 0) if group is not None else 0
+            if group is not None:
+                group._queue_seq = seq + 1
+            key = 'pages%d' % seq
         self.key = key
+        self.max_attempts = int(max_attempts) if max_attempts else max(2, world)
         self._local = 0
+        self._local_returned = []
+        self._local_done = 0
+        self._slot = None          # index into the returned list this rank has reserved
+        self._mine = set()         # items this rank gave back: it leaves them to the others
+        self._attempts = {}
         self.taken = []
+        self.given_back = []
+
+    # -- store helpers (single process: plain attributes)
+    def _add(self, name, n):
+        return int(self.store.add('%s/%s' % (self.key, name), n))
 
     def take(self):
         if self.store is None:
-            i = self._local
-            self._local += 1
+            if self._local < self.n_items:
+                i = self._local
+                self._local += 1
+            elif self._local_returned:
+                i = self._local_returned.pop(0)
+            else:
+                return None
+            self.taken.append(i)
+            return i
+        i = self._add('next', 1) - 1
+        if i < self.n_items:
+            self.taken.append(i)
+            return i
+        import time
+        while True:
+            if self._add('abort', 0):
+                raise QueueAborted('PageQueue %s: an item failed on %d ranks' % (self.key, self.max_attempts))
+            if self._slot is None and self._add('rtake', 0) < self._add('nret', 0):
+                self._slot = self._add('rtake', 1) - 1
+            if self._slot is not None and self._slot < self._add('nret', 0):
+                i = int(self.store.get('%s/ret/%d' % (self.key, self._slot)))
+                self._slot = None
+                if i in self._mine:                    # my own failure: somebody else's turn (not counted as an attempt)
+                    self._put_back(i)
+                    time.sleep(4 * self.POLL_S)
+                    continue
+                self.taken.append(i)
+                return i
+            if self._add('done', 0) >= self.n_items:
+                return None
+            time.sleep(self.POLL_S)
+
+    def _put_back(self, i):
+        slot = self._add('nret', 1) - 1
+        self.store.set('%s/ret/%d' % (self.key, slot), str(int(i)))
+
+    def give_back(self, i):
+        """This rank could not finish item i: another rank takes it."""
+        self.given_back.append(i)
+        self._mine.add(i)
+        if self.store is None:
+            self._attempts[i] = self._attempts.get(i, 0) + 1
+            if self._attempts[i] >= self.max_attempts:
+                raise QueueAborted('PageQueue %s: item %d failed %d times' % (self.key, i, self._attempts[i]))
+            self._local_returned.append(i)
+            return
+        if self._add('att/%d' % i, 1) >= self.max_attempts:
+            self._add('abort', 1)
+            raise QueueAborted('PageQueue %s: item %d failed on %d ranks' % (self.key, i, self.max_attempts))
+        self._put_back(i)
+
+    def done(self, i):
+        if self.store is None:
+            self._local_done += 1
         else:
-            i = int(self.store.add(self.key, 1)) - 1
-        if i >= self.n_items:
-            return None
-        self.taken.append(i)
-        return i
+            self._add('done', 1)
 
     def __iter__(self):
         while True:
             i = self.take()
             if i is None:
                 return
+            before = len(self.given_back)
             yield i
+            if len(self.given_back) == before:
+                self.done(i)
 
 
 def shard_indices(n_items, rank, world):

@@ -75,6 +75,7 @@ class HipContext:
         self._h = h
         self.east_loaded = False
         self.crnn_loaded = False
+        self.options = {}              # what set_option was last called with, per name
 
     def close(self):
         if getattr(self, '_h', None):
@@ -120,6 +121,7 @@ class HipContext:
         'flat_gemm': 1 (default) Dense layers / LSTM input projections / 2x2 convolutions on the 256 x 128 flat GEMM,
         0 on the implicit-GEMM convolution kernel."""
         check(self.lib.ocrhip_set_option(self._h, name.encode(), int(value)))
+        self.options[name] = int(value)
 
     def image_resize_norm(self, images, out_h, out_w):
         """images: (B,H,W,3) uint8 raw or float32 in [0,1], on the GPU -> (B,out_h,out_w,3) float32 normalised

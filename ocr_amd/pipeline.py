@@ -19,6 +19,7 @@ results are (m,4,2) corner arrays.
 import numpy as np
 import torch
 
+from ._lib import OcrHipError
 from .engine import HipContext, F32
 from .utils import image_sizes as S
 from .utils.text import CharTokenizer
@@ -42,6 +43,9 @@ class OcrPipeline:
         self.merge_method = merge_method
         self.max_crop_elems = max_crop_elems
         self.rotated = rotated
+        self._rec_seq = 0              # recogniser calls enqueued so far
+        self._failed_upto = -1         # calls up to this number were in flight when a persistent BiLSTM launch timed out
+        self.lstm_fallbacks = 0        # batches recognised again with one launch per time step after such a time-out
 
     # ---- detection --------------------------------------------------------------------------
     def detect(self, images, maps_override=None):
@@ -128,6 +132,9 @@ class OcrPipeline:
         else:
             packed = self.ctx.crop_resize_pack(images, d_rects, d_box_img, d_inter, d_out_w, d_off, int(off[-1]))
         out = self.ctx.crnn_forward_packed(packed, out_w, compute_dtype=self.compute_dtype)
+        st['seq'] = self._rec_seq
+        self._rec_seq += 1
+        st['out_w'] = out_w
         h_tokens = torch.empty(out['tokens'].shape, dtype=torch.int32, pin_memory=True)
         h_scores = torch.empty(out['scores'].shape, dtype=torch.float32, pin_memory=True)
         h_tokens.copy_(out['tokens'], non_blocking=True)
@@ -147,7 +154,18 @@ class OcrPipeline:
         if st['n'] == 0:
             return out
         st['tokens_ready'].synchronize()
-        self.ctx.check_errors(synchronize=False)        # a timed-out recurrence fails the batch instead of returning garbage
+        if st['seq'] > self._failed_upto:
+            try:
+                self.ctx.check_errors(synchronize=False)    # a timed-out recurrence fails the batch instead of returning garbage
+            except OcrHipError as e:
+                if 'lstm hand-over timed out' not in str(e):
+                    raise
+                # the persistent recurrence did not get the whole GPU (a co-tenant): every recogniser call enqueued so
+                # far counts as failed; each is run again, once, with one launch per time step (no hand-over between
+                # workgroups), in this process
+                self._failed_upto = self._rec_seq - 1
+        if st['seq'] <= self._failed_upto:
+            self._recognise_again(st)
         tokens, scores = st['h_tokens'].numpy(), st['h_scores'].numpy()
         box_img, box_idx = st['box_img'], st['box_idx']
         texts = self.tokenizer.decode_batch(tokens[:st['n']])
@@ -157,6 +175,20 @@ class OcrPipeline:
             o['scores'][i] = score
             o['valid'][i] = True
         return out
+
+    def _recognise_again(self, st):
+        """The recogniser of a batch once more on the crops still packed on the GPU, `lstm_persistent = 0`."""
+        packed = st['_keep'][4]
+        before = self.ctx.options.get('lstm_persistent', 2)
+        self.ctx.set_option('lstm_persistent', 0)
+        try:
+            out = self.ctx.crnn_forward_packed(packed, st['out_w'], compute_dtype=self.compute_dtype)
+            st['h_tokens'].copy_(out['tokens'])
+            st['h_scores'].copy_(out['scores'])
+            self.ctx.check_errors(synchronize=True)
+        finally:
+            self.ctx.set_option('lstm_persistent', before)
+        self.lstm_fallbacks += 1
 
     # ---- end to end -------------------------------------------------------------------------
     def __call__(self, images, maps_override=None):

@@ -91,6 +91,75 @@ def test_two_rank_dynamic_queue_balances_uneven_costs():
     assert [r for _, r in full] == [0 if i in taken0 else 1 for i in range(n_items)]
 
 
+def _retry_worker(rank, world, port, n_items, q):
+    """Rank 1 fails item 3 (its GPU call 'raises'); rank 0 must end up with it.  Then a second queue on the same group
+    starts at zero, and an item nobody can process aborts the queue on every rank."""
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from ocr_amd import dist as D
+    grp = D.init_from_env(backend='gloo')
+    queue = D.PageQueue(n_items, grp)
+    grp.dist.barrier()
+    local, failed = [], []
+    while True:
+        i = queue.take()
+        if i is None:
+            break
+        time.sleep(0.01)
+        # item 3 fails on whichever rank gets it first, and only there
+        if i == 3 and not grp.store.add('test/failed3', 0):
+            grp.store.add('test/failed3', 1)
+            failed.append(i)
+            queue.give_back(i)
+            continue
+        local.append((i, {'page': i, 'rank': rank}))
+        queue.done(i)
+    full = D.gather_results(local, n_items, grp, dst=0)
+    grp.dist.barrier()
+    # a second queue of the same job: its own keys, starts at zero
+    second = D.PageQueue(5, grp)
+    assert second.key != queue.key
+    got2 = list(second)
+    full2 = D.gather_results([(i, i * i) for i in got2], 5, grp, dst=0)
+    grp.dist.barrier()
+    # an item that fails everywhere: QueueAborted on every rank instead of a hang
+    third = D.PageQueue(2, grp)
+    aborted = False
+    try:
+        for i in third:
+            if i == 1:
+                third.give_back(i)
+    except D.QueueAborted:
+        aborted = True
+    grp.dist.barrier()
+    q.put((rank, failed, queue.taken, None if full is None else [(f['page'], f['rank']) for f in full], full2, aborted))
+    grp.dist.destroy_process_group()
+
+
+def test_a_failed_batch_goes_back_to_the_queue_and_another_rank_takes_it():
+    world, n_items = 2, 9
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_retry_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, failed0, taken0, full, full2, ab0), (_, failed1, taken1, none, none2, ab1) = got
+    assert none is None and none2 is None
+    assert sorted(failed0 + failed1) == [3]                                # exactly one rank failed it
+    loser = 0 if failed0 else 1
+    assert [p for p, _ in full] == list(range(n_items))                    # nothing lost, nothing twice
+    assert dict(full)[3] == 1 - loser                                      # the OTHER rank processed the failed batch
+    assert (taken0 if loser == 0 else taken1).count(3) == 1
+    assert full2 == [0, 1, 4, 9, 16]
+    assert ab0 and ab1
+
+
 def test_gather_results_rejects_lost_and_duplicate_items():
     import pytest
     from ocr_amd import dist as D
@@ -101,6 +170,13 @@ def test_gather_results_rejects_lost_and_duplicate_items():
         D.gather_results([(0, 'a'), (0, 'b')], 2, None)
     q = D.PageQueue(3)
     assert list(q) == [0, 1, 2] and q.take() is None
+    # single process: a returned item comes back once, a second failure of the same item gives up
+    q = D.PageQueue(2)
+    assert q.take() == 0
+    q.give_back(0)
+    assert q.take() == 1 and q.take() == 0
+    with pytest.raises(D.QueueAborted):
+        q.give_back(0)
 
 
 def test_single_process_is_a_no_op():

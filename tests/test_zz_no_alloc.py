@@ -53,3 +53,33 @@ def test_static_decode_equals_decode_on_two_calls_in_a_row():
         assert int(out['counts'][0]) == -7
     finally:
         ctx.close()
+
+
+def test_static_decode_takes_no_device_memory():
+    """The property the entry point exists for: on a FRESH handle (its grow-only staging buffer has never been grown)
+    the first call, on a map larger than any earlier one of the process, leaves the device's free memory where it was.
+    Outputs are allocated by the caller beforehand; `torch.cuda.mem_get_info` reads the driver's figure, which sees the
+    library's hipMalloc calls as well as torch's."""
+    from ocr_amd import synth
+    from ocr_amd.engine import HipContext
+    _, maps, _ = synth.make_pages(43, 6, 1024, 1024, 150)           # 6 maps of 256 x 256: 1536 chunks of staging
+    d = torch.from_numpy(maps).cuda()
+    B, mh, mw, _ = d.shape
+    cap = mh * mw
+    outs = [torch.empty((B, cap, 4), dtype=torch.float32, device='cuda'), torch.empty((B, cap, 8), dtype=torch.float32, device='cuda'),
+            torch.empty((B, cap), dtype=torch.float32, device='cuda'), torch.empty((B, cap), dtype=torch.int32, device='cuda'),
+            torch.empty((B,), dtype=torch.int32, device='cuda')]
+    ctx = HipContext(0)
+    try:
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        rc = ctx.lib.ocrhip_east_decode_static(ctx._h, p(d), B, mh, mw, 1024, 1024, 0.35, cap, *[p(t) for t in outs], stream)
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+        assert rc == 0, ctx.lib.ocrhip_last_error()
+        assert free1 == free0, 'the static entry point changed the free device memory by %d bytes' % (free0 - free1)
+        assert int(outs[4].sum()) > 0
+    finally:
+        ctx.close()
