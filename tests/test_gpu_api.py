@@ -54,8 +54,15 @@ def test_east_input_not_multiple_of_32(models):
         np.testing.assert_array_equal(y[b], oimg.normalize_mean_std(oimg.aa_resize_numpy(f[b], 32, 160)))
         np.testing.assert_allclose(y[b], oimg.normalize_mean_std(oimg.aa_resize_torch(f[b], 32, 160)), rtol=0, atol=2e-6)
     out = east.infer(img)['output']
-    ref = nets.east_forward(ep, ref_in[None])[0].numpy()
-    np.testing.assert_allclose(out, ref, rtol=2e-4, atol=2e-5)
+    # the network on this page, at the tolerance of every other map comparison (1e-4 relative): the oracle network on
+    # the SAME input the GPU network read (the NumPy restatement of the filter, bit-identical to the GPU's resize)
+    ref = nets.east_forward(ep, oimg.prepare_east_input(img, resize='numpy')[None])[0].numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5)
+    # against the oracle network on torch's resize of the page the maps differ by what the two INPUTS differ: torch
+    # rounds the filter taps differently (inputs up to 2e-5 apart, above), and 20 layers carry that to ~2e-4 of a map
+    # value - an input difference of the resize restatement, not a network one
+    ref_t = nets.east_forward(ep, ref_in[None])[0].numpy()
+    np.testing.assert_allclose(out, ref_t, rtol=2e-4, atol=2e-5)
 
 
 def test_base_ocr_infer_and_ocr_function(models):

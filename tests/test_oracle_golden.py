@@ -181,3 +181,44 @@ def test_pad_repeat_last():
     assert out.shape == (4, 5, 1)
     np.testing.assert_array_equal(out[:2, 3:, 0], np.array([[2, 2], [5, 5]], dtype=np.float32))
     np.testing.assert_array_equal(out[2:, :, 0], np.tile(out[1:2, :, 0], (2, 1)))
+
+
+# ------------------------------------------------------------------ the C LANMS against the pinned NumPy one
+# oracle/lanms_c.c serves the page-scale checks (thousands of candidates); it is itself held to oracle/nms.py, which the
+# reference's known answers above pin: same boxes, mask, order and iteration count.
+
+def _same_as_numpy_lanms(boxes, scores, **kwargs):
+    from oracle import lanms_c
+    ref = onms.lanms(boxes, scores, **kwargs)
+    got = lanms_c.lanms(boxes, scores, **kwargs)
+    if kwargs.get('merge_method', 'union') == 'union':
+        np.testing.assert_array_equal(got[0], ref[0])               # min / max only: exact
+    else:
+        np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=2e-6)
+    if scores is not None:
+        np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+    np.testing.assert_array_equal(got[3], ref[3])
+    assert got[4] == ref[4]
+    return ref
+
+
+@pytest.mark.parametrize('kwargs', [
+    dict(nms_threshold=0.1, merge_threshold=0.1), dict(nms_threshold=0.1, merge_threshold=0.1, merge_method='average'),
+    dict(nms_threshold=0.01, merge_threshold=0.1), dict(nms_threshold=0.1, merge_threshold=0.01)])
+def test_c_lanms_equals_numpy_lanms_on_the_reference_known_answers(kwargs):
+    _same_as_numpy_lanms(CHAIN, None, **kwargs)
+
+
+@pytest.mark.parametrize('seed,method', [(21, 'union'), (22, 'union'), (21, 'average')])
+def test_c_lanms_equals_numpy_lanms_on_decoded_pages(seed, method):
+    """Two synthetic 512 x 512 pages decoded by the oracle (more than 1000 candidates each), the detector's defaults
+    (merge 0.3, NMS 0.2: both passes run)."""
+    from ocr_amd import synth
+    from oracle import boxes as obox, east_decode as odec
+    _, maps, _ = synth.make_pages(seed, 1, 512, 512, 30)
+    dec = odec.decode_map(maps[0], (512, 512), threshold=0.35)
+    boxes, scores = obox.poly_to_xyxy(dec['boxes']), dec['scores']
+    assert len(boxes) > 1000
+    ref = _same_as_numpy_lanms(boxes, scores, nms_threshold=0.2, merge_threshold=0.3, merge_method=method)
+    assert 10 <= int(ref[2].sum()) <= 60 and ref[4] >= 2
