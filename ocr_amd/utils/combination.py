@@ -4,8 +4,10 @@ Same rules and results as the reference's `combine_boxes` chain
 (utils/image/bounding_box/combination.py:150-361): horizontal grouping (same line), vertical
 grouping (stacked lines of similar height), then grouping of results that contain each other, with
 the rows of a paragraph merged per text line and aligned on their left border.  Connected
-components are found with a union-find; groups are listed by their smallest member and members in
-ascending order before the positional sort, which is the order the reference produces.
+components are found with a union-find and kept as one label per box; a level of grouping then is
+ONE stable ordering of the boxes by (group, position) whose runs give every group's hull, members
+and index lists (groups in the order of their smallest member, ties of position in ascending box
+order: the order the reference produces).
 
 This is host-side bookkeeping on at most a few hundred kept boxes per page; it decides which crops
 the recogniser sees when `BaseOCR.infer(combine=True)` (models/ocr/base_ocr.py:154-157).
@@ -13,8 +15,9 @@ the recogniser sees when `BaseOCR.infer(combine=True)` (models/ocr/base_ocr.py:1
 import numpy as np
 
 
-def _components(mask):
-    """Connected components of the symmetric closure of a boolean adjacency matrix."""
+def _labels(mask):
+    """Connected components of the symmetric closure of a boolean adjacency matrix, as one label per node: the
+    smallest node of its component (union-find with path halving)."""
     n = len(mask)
     parent = list(range(n))
 
@@ -28,79 +31,74 @@ def _components(mask):
         ra, rb = find(int(a)), find(int(b))
         if ra != rb:
             parent[max(ra, rb)] = min(ra, rb)
-    groups = {}
-    for i in range(n):
-        groups.setdefault(find(i), []).append(i)
-    return [groups[k] for k in sorted(groups)]
+    return np.fromiter((find(i) for i in range(n)), dtype=np.int64, count=n)
 
 
-def _union(boxes):
-    if len(boxes) == 1:
-        return boxes[0]
-    return np.concatenate([boxes[:, :2].min(axis=0), boxes[:, 2:].max(axis=0)])
+def _runs(labels, key=None):
+    """Nodes ordered by (label, key, node) and the [start, end) of every label's run in that order.  Labels are the
+    smallest member of a group, so the runs come in the order of the groups' smallest members; the sort is stable, so
+    equal keys (and key=None) keep the members in ascending order."""
+    order = np.argsort(labels, kind='stable') if key is None else np.lexsort((key, labels))
+    lab = labels[order]
+    starts = np.flatnonzero(np.concatenate([[True], lab[1:] != lab[:-1]]))
+    return order, starts, np.concatenate([starts[1:], [len(order)]])
 
 
-def _flatten(lists):
-    if len(lists) == 1:
-        return lists[0]
-    out = []
-    for item in lists:
-        out.extend(item)
-    return out
+def _hulls(boxes, starts):
+    """Bounding box of every run of `boxes` (already ordered; runs start at `starts`)."""
+    return np.concatenate([np.minimum.reduceat(boxes[:, :2], starts), np.maximum.reduceat(boxes[:, 2:], starts)], axis=1)
 
 
-def _merge_rows(rows, indices):
-    """Rows of one paragraph that overlap vertically by half the mean height become one row."""
-    if len(rows) < 2:
-        return rows, indices
-    h_mean = np.mean(rows[:, 3] - rows[:, 1])
-    overlap = np.maximum(0., np.minimum(rows[:, None, 3], rows[None, :, 3]) -
-                         np.maximum(rows[:, None, 1], rows[None, :, 1])) / h_mean
-    groups = _components(overlap >= 0.5)
-    return (np.array([_union(rows[g]) for g in groups]),
-            [_flatten([indices[i] for i in g]) for g in groups])
+def _fuse_text_lines(rows, words):
+    """Rows of one paragraph that overlap vertically by half the mean row height become one row (its hull; the word
+    lists concatenated in row order)."""
+    top, bottom = rows[:, 1], rows[:, 3]
+    shared = np.maximum(0., np.minimum(bottom[:, None], bottom[None, :]) - np.maximum(top[:, None], top[None, :]))
+    order, starts, ends = _runs(_labels(shared / np.mean(bottom - top) >= 0.5))
+    return _hulls(rows[order], starts), [[w for i in order[a:b] for w in words[i]] for a, b in zip(starts, ends)]
 
 
-def _align_rows(rows, mode, center_threshold=1e-2):
-    if len(rows) == 1:
-        return rows
+def _justify(rows, mode, center_threshold):
+    """Rows of a paragraph share their left (or right) border; 'auto' leaves centred paragraphs (every row centre within
+    `center_threshold` of the mean centre) alone and aligns the others on the left."""
     if mode == 'auto':
-        xc = (rows[:, 0] + rows[:, 2]) / 2.
-        if not np.all(np.abs(xc - np.mean(xc)) < center_threshold):
-            mode = 'left'
+        centre = (rows[:, 0] + rows[:, 2]) / 2.
+        mode = 'left' if np.abs(centre - np.mean(centre)).max() >= center_threshold else None
     if mode == 'left':
-        rows[:, 0] = np.min(rows[:, 0])
+        rows[:, 0] = rows[:, 0].min()
     elif mode == 'right':
-        rows[:, 2] = np.max(rows[:, 2])
+        rows[:, 2] = rows[:, 2].max()
     return rows
 
 
-def _group(boxes, indices, groups, sort_axis, rows=None, check_rows=None, align_borders=None,
-           center_threshold=1e-2):
-    if rows is not None:
-        check_rows = True if check_rows is None else check_rows
-        align_borders = 'auto' if align_borders is None else align_borders
-    out_boxes, out_indices, members = [], [], []
-    for g in groups:
-        if len(g) > 1:
-            g = sorted(g, key=lambda i: boxes[i, sort_axis])
-        sub = boxes[g]
-        out_boxes.append(_union(sub))
-        if rows is None:
-            out_indices.append([indices[i] for i in g])
-            members.append(sub)
-        elif len(g) == 1:
-            out_indices.append(indices[g[0]])
-            members.append(rows[g[0]])
-        else:
-            out_indices.append(_flatten([indices[i] for i in g]))
-            members.append(np.concatenate([rows[i] for i in g], axis=0))
-    if check_rows:
-        merged = [_merge_rows(r, i) for r, i in zip(members, out_indices)]
-        members, out_indices = [m[0] for m in merged], [m[1] for m in merged]
-    if align_borders:
-        members = [_align_rows(r, align_borders, center_threshold) for r in members]
-    return np.array(out_boxes), out_indices, members
+def _group(boxes, indices, labels, sort_axis, rows=None, check_rows=None, align_borders=None, center_threshold=1e-2):
+    """One level of grouping from a label per box.  Boxes are ordered once by (group, position along `sort_axis`);
+    every group's hull, members and index lists are runs of that order.
+    rows is None (words -> lines, lines -> paragraphs): members[g] = the ordered boxes of group g, indices[g] = their
+    index entries.  rows given (paragraphs that contain each other): members[g] = the rows of all its members, fused
+    per text line and justified; indices[g] = one word list per row."""
+    if len(boxes) == 0:
+        return np.array([]), [], []
+    order, starts, ends = _runs(labels, boxes[:, sort_axis])
+    ordered = boxes[order]
+    hulls = _hulls(ordered, starts)
+    if rows is None:
+        return (hulls, [[indices[i] for i in order[a:b]] for a, b in zip(starts, ends)],
+                [ordered[a:b] for a, b in zip(starts, ends)])
+    check_rows = True if check_rows is None else check_rows
+    align_borders = 'auto' if align_borders is None else align_borders
+    members, out_indices = [], []
+    for a, b in zip(starts, ends):
+        group = order[a:b]
+        r = rows[group[0]] if b - a == 1 else np.concatenate([rows[i] for i in group], axis=0)
+        words = indices[group[0]] if b - a == 1 else [w for i in group for w in indices[i]]
+        if check_rows and len(r) > 1:
+            r, words = _fuse_text_lines(r, words)
+        if align_borders and len(r) > 1:
+            r = _justify(r, align_borders, center_threshold)
+        members.append(r)
+        out_indices.append(words)
+    return hulls, out_indices, members
 
 
 def _as_boxes(boxes):
@@ -131,7 +129,7 @@ def combine_boxes_horizontal(boxes, *, indices=None, h_factor=1.5, x_threshold=N
     frac = np.zeros_like(overlap_y)
     np.divide(overlap_y, max_h, out=frac, where=max_h > 0)
     mask = (gap <= x_threshold) & (frac >= y_overlap_threshold)
-    return _group(boxes, indices, _components(mask), 0)
+    return _group(boxes, indices, _labels(mask), 0)
 
 
 def combine_boxes_vertical(boxes, *, indices=None, y_threshold=None, h_threshold=0.02, x_overlap_threshold=0.,
@@ -159,7 +157,7 @@ def combine_boxes_vertical(boxes, *, indices=None, y_threshold=None, h_threshold
     else:
         x_mask = overlap_x / np.minimum(shifted_w[:, None], shifted_w[None, :]) > x_overlap_threshold
     mask = (gap <= y_threshold) & (h_diff <= h_threshold) & x_mask
-    return _group(boxes, indices, _components(mask), 1)
+    return _group(boxes, indices, _labels(mask), 1)
 
 
 def _ioa_matrix(boxes):
@@ -178,7 +176,7 @@ def combine_boxes_overlap(boxes, indices=None, overlap_threshold=0.5, rows=None,
     if indices is None:
         indices = list(range(len(boxes)))
     mask = _ioa_matrix(boxes) > overlap_threshold
-    return _group(boxes, indices, _components(mask), 1, rows=rows, check_rows=kwargs.get('check_rows'),
+    return _group(boxes, indices, _labels(mask), 1, rows=rows, check_rows=kwargs.get('check_rows'),
                   align_borders=kwargs.get('align_borders'), center_threshold=kwargs.get('center_threshold', 1e-2))
 
 
