@@ -217,10 +217,11 @@ const int kMergeCin[7] = {1024, 128, 384, 64, 192, 32, 32};
 const int kMergeCout[7] = {128, 128, 64, 64, 32, 32, 32};
 const int kMergeKs[7] = {1, 3, 1, 3, 1, 3, 3};
 
-void record(std::map<std::string, Activation>& taps, const char* name, const float* p, int64_t b, int64_t h, int64_t w,
-            int64_t c) {
+void record(std::map<std::string, Activation>& taps, const char* name, const void* p, int64_t b, int64_t h, int64_t w,
+            int64_t c, bool bf16 = false) {
     Activation a;
     a.ptr = p;
+    a.bf16 = bf16;
     a.shape[0] = b; a.shape[1] = h; a.shape[2] = w; a.shape[3] = c;
     taps[name] = a;
 }
@@ -241,6 +242,15 @@ int read_activation(const std::map<std::string, Activation>& taps, const char* n
         return OCRHIP_ECAP;
     }
     OCR_HIP_CHECK(hipDeviceSynchronize());
+    if (it->second.bf16) {
+        std::vector<uint16_t> raw((size_t)k);
+        OCR_HIP_CHECK(hipMemcpy(raw.data(), it->second.ptr, (size_t)k * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < k; ++i) {
+            const uint32_t bits = (uint32_t)raw[(size_t)i] << 16;
+            std::memcpy(dst + i, &bits, sizeof(float));
+        }
+        return OCRHIP_OK;
+    }
     OCR_HIP_CHECK(hipMemcpy(dst, it->second.ptr, (size_t)k * sizeof(float), hipMemcpyDeviceToHost));
     return OCRHIP_OK;
 }
@@ -299,7 +309,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     if (!h) return OCRHIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.w_wino4.release(); L.w_wino4b.release(); L.w_wino4c.release(); L.w_bf16.release(); L.bias.release(); L.w_gemm.release(); L.bias_gemm.release(); };
+    auto free_layer = [](ConvLayer& L) { L.w_f32.release(); L.w_wino.release(); L.w_wino4.release(); L.w_wino4b.release(); L.w_wino4c.release(); L.w_bf16.release(); L.w_bf16t.release(); L.bias.release(); L.w_gemm.release(); L.bias_gemm.release(); };
     for (auto& L : h->crnn.rconv) free_layer(L);
     for (auto& L : h->east.vgg) free_layer(L);
     for (auto& L : h->east.merge) free_layer(L);
@@ -316,7 +326,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     }
     free_layer(h->crnn.pred);
     for (auto& b : h->crnn.act) b.release();
-    for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits, &h->crnn.meta, &h->crnn.lstm_counters, &h->crnn.pmax, &h->crnn.pidx})
+    for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits, &h->crnn.seq16, &h->crnn.meta, &h->crnn.lstm_counters, &h->crnn.pmax, &h->crnn.pidx})
         b->release();
     h->crnn.ring.release();
     if (h->crnn.lstm_err_host) (void)hipHostFree(h->crnn.lstm_err_host);
@@ -381,6 +391,57 @@ int ocrhip_east_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n
     return OCRHIP_OK;
 }
 
+// The detector on bfloat16 tensors: the first layer and the heads compute in float32 (3 and 32 input channels are no
+// matrix work), every other layer is a bfloat16 tile kernel with float32 accumulation; activations are bfloat16 in HBM.
+// The x2 upsampling + concatenation of a merge stage is one bandwidth-bound pass in front of its 1x1 convolution.
+static int east_forward_bf16(EastNet& net, const void* d_img, int B, int H, int W, int in_dtype, float* d_maps, hipStream_t s) {
+    const size_t px = (size_t)B * H * W;
+    unsigned char* act0 = net.act[0].as<unsigned char>();          // 256 bytes per input pixel
+    uint16_t* T = reinterpret_cast<uint16_t*>(act0);               // upsample + concat of a merge stage: <= 24 bytes per input pixel
+    uint16_t* X = reinterpret_cast<uint16_t*>(act0 + px * 64);     // <= 128 bytes per input pixel
+    uint16_t* Y = net.act[1].as<uint16_t>();                       // 128 bytes per input pixel
+    const int pool_c[5] = {64, 128, 256, 512, 512};
+    OCR_TRY(launch_conv_first(net.vgg[0], d_img, in_dtype == OCRHIP_U8, X, B, H, W, 0, s, true));
+    const uint16_t* cur = X;
+    int ch = H, cw = W, np = 0;
+    for (int i = 1; i < 13; ++i) {
+        uint16_t* dst = kEastVggPool[i] ? net.pool[np].as<uint16_t>() : ((cur == X) ? Y : X);
+        OCR_TRY(launch_conv3_bf16t(net.vgg[i], cur, dst, B, 1, ch, cw, 0, kEastVggPool[i] ? 1 : 0, true, s));
+        if (kEastVggPool[i]) {
+            ch /= 2; cw /= 2;
+            const std::string name = "pool" + std::to_string(np + 1);
+            record(net.taps, name.c_str(), dst, B, ch, cw, pool_c[np], true);
+            ++np;
+        }
+        cur = dst;
+    }
+    const uint16_t* up = net.pool[4].as<uint16_t>();
+    int up_c = 512;
+    int mh = H / 32, mw = W / 32;
+    int k = 0;
+    for (int stage = 0; stage < 3; ++stage) {
+        mh *= 2; mw *= 2;
+        const uint16_t* res = net.pool[3 - stage].as<uint16_t>();
+        OCR_TRY(launch_upcat16(up, res, T, B, mh, mw, up_c, kMergeCin[k] - up_c, s));
+        OCR_TRY(launch_gemm_bf16t(net.merge[k], T, X, false, (int64_t)B * mh * mw, 0, 0, 0, true, s));
+        ++k;
+        OCR_TRY(launch_conv3_bf16t(net.merge[k], X, Y, B, 1, mh, mw, 0, 0, true, s));
+        ++k;
+        const uint16_t* last = Y;
+        if (stage == 2) {
+            OCR_TRY(launch_conv3_bf16t(net.merge[k], Y, X, B, 1, mh, mw, 0, 0, true, s));
+            ++k;
+            last = X;
+        }
+        const std::string name = "merge" + std::to_string(k);
+        record(net.taps, name.c_str(), last, B, mh, mw, kMergeCout[k - 1], true);
+        up = last;
+        up_c = kMergeCout[k - 1];
+    }
+    OCR_TRY(launch_east_heads16(net.head, up, d_maps, (int64_t)B * mh * mw, s));
+    return OCRHIP_OK;
+}
+
 int ocrhip_east_forward(ocrhip_handle h, const void* d_img, int B, int H, int W, int in_dtype, int compute_dtype,
                         float* d_maps, ocrhip_stream stream) {
     OCR_HANDLE(h);
@@ -403,6 +464,7 @@ int ocrhip_east_forward(ocrhip_handle h, const void* d_img, int B, int H, int W,
     float* A = net.act[0].as<float>();
     float* Bf = net.act[1].as<float>();
     net.taps.clear();
+    if (compute_dtype == OCRHIP_BF16 && h->bf16_tensors) return east_forward_bf16(net, d_img, B, H, W, in_dtype, d_maps, s);
 
     // VGG16-BN body; a convolution followed by 'M' writes the pooled tensor directly
     OCR_TRY(launch_conv_first(net.vgg[0], d_img, in_dtype == OCRHIP_U8, A, B, H, W, 0, s));
@@ -822,6 +884,101 @@ static int crnn_report_timeout(CrnnNet& net, hipStream_t s) {
     return OCRHIP_EHIP;
 }
 
+// ---- the VGG recogniser on bfloat16 tensors (`compute_dtype = OCRHIP_BF16`, option bf16_tensors = 1)
+// Crops of one width are tiled side by side in every 3x3 layer (one zero column apart, two under 2x2 pooling): the
+// 32-column tiles are full whatever the crop width.
+static int crnn_features16(CrnnNet& net, const float* x, int n, int Wpad, uint16_t* feats16, hipStream_t s) {
+    const int T = Wpad / 4 - 1;
+    const size_t nW = (size_t)n * Wpad;
+    OCR_TRY(net.act[0].reserve(nW * 512 * sizeof(float)));
+    OCR_TRY(net.act[1].reserve(nW * 256 * sizeof(float)));
+    uint16_t* A = net.act[0].as<uint16_t>();
+    uint16_t* Bf = net.act[1].as<uint16_t>();
+    OCR_TRY(launch_conv_first(net.conv[0], x, false, A, n, 64, Wpad, 1, s, true));                      // (n,32,W/2,32)
+    OCR_TRY(launch_conv3_bf16t(net.conv[1], A, Bf, 1, n, 32, Wpad / 2, 2, 1, true, s));                  // (n,16,W/4,64)
+    OCR_TRY(launch_conv3_bf16t(net.conv[2], Bf, A, 1, n, 16, Wpad / 4, 1, 0, true, s));                  // (n,16,W/4,128)
+    OCR_TRY(launch_conv3_bf16t(net.conv[3], A, Bf, 1, n, 16, Wpad / 4, 1, 2, true, s));                  // (n,8,W/4,128)
+    OCR_TRY(launch_conv3_bf16t(net.conv[4], Bf, A, 1, n, 8, Wpad / 4, 1, 0, true, s));                   // (n,8,W/4,256)
+    OCR_TRY(launch_conv3_bf16t(net.conv[5], A, Bf, 1, n, 8, Wpad / 4, 1, 2, true, s));                   // (n,4,W/4,256)
+    OCR_TRY(launch_gemm_bf16t(net.conv[6], Bf, A, false, (int64_t)n * 3 * T, n, 4, Wpad / 4, true, s));  // (n,3,T,256)
+    OCR_TRY(launch_mean_rows16(A, feats16, n, 3, T, net.feat_c, s));
+    return OCRHIP_OK;
+}
+
+static int crnn_sequence16(CrnnNet& net, const uint16_t* feats16, int n, int64_t R, int Tmax, const int* host_T,
+                           const int* d_T, const int* d_row0, const int* d_active, float* logits, hipStream_t s) {
+    const int Hd = net.hidden;
+    OCR_REQUIRE(R < (1ll << 31), "crnn: too many time steps in one batch");
+    OCR_TRY(net.xw.reserve((size_t)2 * R * 4 * Hd * sizeof(float)));
+    OCR_TRY(net.hbuf.reserve((size_t)2 * 2 * n * Hd * sizeof(float)));
+    OCR_TRY(net.cbuf.reserve((size_t)2 * n * Hd * sizeof(float)));
+    OCR_TRY(net.seq.reserve((size_t)R * 2 * Hd * sizeof(float)));
+    OCR_TRY(net.lin.reserve((size_t)2 * R * Hd * sizeof(float)));
+    OCR_TRY(net.seq16.reserve((size_t)R * 2 * Hd * sizeof(uint16_t)));
+    if (!net.lstm_counters.ptr) {
+        OCR_TRY(net.lstm_counters.reserve((kLstmCounterCount + kLstmErrorWords) * sizeof(unsigned)));
+        OCR_HIP_CHECK(hipMemsetAsync(net.lstm_counters.ptr, 0, (kLstmCounterCount + kLstmErrorWords) * sizeof(unsigned), s));
+    }
+    if (!net.lstm_err_host) {
+        OCR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&net.lstm_err_host), CrnnNet::kErrSlots * sizeof(unsigned), hipHostMallocDefault));
+        for (int i = 0; i < CrnnNet::kErrSlots; ++i) net.lstm_err_host[i] = 0;
+    }
+    OCR_HIP_CHECK(hipMemsetAsync(net.lstm_counters.as<unsigned>() + kLstmCounterCount, 0, kLstmErrorWords * sizeof(unsigned), s));
+    const uint16_t* layer_in = feats16;
+    uint16_t* seq16 = net.seq16.as<uint16_t>();
+    for (int l = 0; l < 2; ++l) {
+        float* xw_f = net.xw.as<float>();
+        float* xw_b = xw_f + (size_t)R * 4 * Hd;
+        OCR_TRY(launch_gemm_bf16t(net.wih[l][0], layer_in, xw_f, true, R, 0, 0, 0, false, s));
+        OCR_TRY(launch_gemm_bf16t(net.wih[l][1], layer_in, xw_b, true, R, 0, 0, 0, false, s));
+        {
+            ProfScope prof("lstm_layer16(T steps)", 2.0 * 2 * 4.0 * Hd * Hd * (double)(R - n),
+                           4.0 * (2.0 * R * 4 * Hd) + 2.0 * (double)R * 2 * Hd + 2.0 * 2 * 4 * Hd * Hd * Tmax, s);
+            int rc = launch_lstm_layer16(xw_f, xw_b, net.whh[l][0].as<float>(), net.whh[l][1].as<float>(), net.hbuf.as<uint16_t>(),
+                                         net.cbuf.as<float>(), seq16, n, Tmax, Hd, d_T, d_row0, d_active, net.lstm_counters.as<unsigned>(), s);
+            if (rc != OCRHIP_OK && rc != OCRHIP_ESTATE) return rc;
+            if (rc == OCRHIP_ESTATE) {
+                // one float32 launch per time step (other hidden sizes, lstm_persistent = 0, a device that cannot hold the
+                // persistent grid): float32 h, the layer's output rounded to bfloat16 afterwards
+                float* hb0 = net.hbuf.as<float>();
+                float* hb1 = hb0 + (size_t)2 * n * Hd;
+                int first = 0;
+                for (int step = 0; step < Tmax; ++step) {
+                    if (host_T)
+                        while (first < n && host_T[first] <= step) ++first;
+                    const float* hp = (step & 1) ? hb1 : hb0;
+                    float* hn = (step & 1) ? hb0 : hb1;
+                    OCR_TRY(launch_lstm_step(xw_f, xw_b, net.whh[l][0].as<float>(), net.whh[l][1].as<float>(), hp, hn,
+                                             net.cbuf.as<float>(), net.seq.as<float>(), n, Tmax, step, d_T, d_row0, first, Hd, s));
+                }
+                OCR_TRY(launch_f32_to_bf16(net.seq.as<float>(), seq16, R * 2 * Hd, s));
+            }
+        }
+        uint16_t* lin = net.lin.as<uint16_t>() + (size_t)l * R * Hd;
+        OCR_TRY(launch_gemm_bf16t(net.linear[l], seq16, lin, false, R, 0, 0, 0, false, s));
+        record(net.taps, l == 0 ? "seq0" : "seq1", lin, 1, R, Hd, 1, true);
+        layer_in = lin;
+    }
+    OCR_TRY(launch_gemm_bf16t(net.pred, layer_in, logits, true, R, 0, 0, 0, false, s));
+    if (net.calls_started - net.calls_checked >= (uint64_t)CrnnNet::kErrSlots) {
+        OCR_HIP_CHECK(hipStreamSynchronize(s));
+        OCR_TRY(crnn_report_timeout(net, s));
+    }
+    unsigned* slot = net.lstm_err_host + net.calls_started % CrnnNet::kErrSlots;
+    *slot = CrnnNet::kErrPending;
+    OCR_HIP_CHECK(hipMemcpyAsync(slot, net.lstm_counters.as<unsigned>() + kLstmCounterCount, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    ++net.calls_started;
+    return OCRHIP_OK;
+}
+
+// whether a forward call runs on the bfloat16-tensor kernels: bfloat16 asked for, the option on, the VGG extractor
+// (the ResNet extractor keeps the float32-tensor kernels with rounded operands) and bfloat16 tile weights for every layer
+static bool crnn_use_bf16_tensors(const ocrhip_ctx* h, int compute_dtype) {
+    const CrnnNet& net = h->crnn;
+    return compute_dtype == OCRHIP_BF16 && h->bf16_tensors && net.backbone == 0 && net.conv[1].w_bf16t.ptr && net.pred.w_bf16t.ptr &&
+           net.wih[0][0].w_bf16t.ptr && net.hidden % 32 == 0;
+}
+
 int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, int compute_dtype, float* d_logits,
                         int* d_tokens, float* d_scores, ocrhip_stream stream) {
     OCR_HANDLE(h);
@@ -844,6 +1001,19 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
     OCR_TRY(net.feats.reserve((size_t)R * Fc * sizeof(float)));
     float* feats = net.feats.as<float>();
     net.taps.clear();
+    if (crnn_use_bf16_tensors(h, compute_dtype)) {
+        uint16_t* feats16 = net.feats.as<uint16_t>();
+        OCR_TRY(crnn_features16(net, reinterpret_cast<const float*>(d_crops), n, Wpad, feats16, s));
+        record(net.taps, "features", feats16, n, T, Fc, 1, true);
+        float* lg = d_logits;
+        if (!lg) {
+            OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));
+            lg = net.logits.as<float>();
+        }
+        OCR_TRY(crnn_sequence16(net, feats16, n, R, T, nullptr, nullptr, nullptr, nullptr, lg, s));
+        if (d_tokens) OCR_TRY(launch_ctc_greedy(lg, n, T, net.vocab, net.vocab, nullptr, nullptr, 0, d_tokens, d_scores, s));
+        return OCRHIP_OK;
+    }
     OCR_TRY(crnn_features(net, reinterpret_cast<const float*>(d_crops), n, Wpad, feats, s));
     record(net.taps, "features", feats, n, T, Fc, 1);
     float* logits = d_logits;
@@ -909,6 +1079,7 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
     // feature extractor: one pass per group of equal width, split so that a pass stays within the workspace budget
     const int64_t max_elems = net.backbone ? (1ll << 18) : (1ll << 20);      // n_group * Wpad per pass (2 GB per buffer at most)
     const float* x = reinterpret_cast<const float*>(d_packed);
+    const bool tensors16 = crnn_use_bf16_tensors(h, compute_dtype);
     int64_t off = 0;
     for (int i = 0; i < n;) {
         const int w = out_w[i];
@@ -917,12 +1088,25 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
         const int per_pass = (int)std::max<int64_t>(1, max_elems / w);
         for (int c0 = i; c0 < j; c0 += per_pass) {
             const int c1 = std::min(j, c0 + per_pass);
-            OCR_TRY(crnn_features(net, x + off, c1 - c0, w, feats + (size_t)meta[n + c0] * Fc, s));
+            if (tensors16)
+                OCR_TRY(crnn_features16(net, x + off, c1 - c0, w, net.feats.as<uint16_t>() + (size_t)meta[n + c0] * Fc, s));
+            else
+                OCR_TRY(crnn_features(net, x + off, c1 - c0, w, feats + (size_t)meta[n + c0] * Fc, s));
             off += (int64_t)(c1 - c0) * 64 * w;
         }
         i = j;
     }
-    record(net.taps, "features", feats, 1, R, Fc, 1);
+    record(net.taps, "features", feats, 1, R, Fc, 1, tensors16);
+    if (tensors16) {
+        float* lg = d_logits;
+        if (!lg) {
+            OCR_TRY(net.logits.reserve((size_t)R * net.vocab * sizeof(float)));
+            lg = net.logits.as<float>();
+        }
+        OCR_TRY(crnn_sequence16(net, net.feats.as<uint16_t>(), n, R, Tmax, meta.data(), d_T, d_row0, d_active, lg, s));
+        if (d_tokens) OCR_TRY(launch_ctc_greedy(lg, n, t_stride, net.vocab, net.vocab, d_T, d_row0, 0, d_tokens, d_scores, s));
+        return OCRHIP_OK;
+    }
     float* logits = d_logits;
     const bool fused = !logits && crnn_can_fuse_ctc(net);
     if (!logits && !fused) {
@@ -996,6 +1180,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "fuse_ctc") == 0) {
         OCR_REQUIRE(value == 0 || value == 1, "set_option: fuse_ctc is 0 or 1");
         h->fuse_ctc = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "bf16_tensors") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: bf16_tensors is 0 or 1");
+        h->bf16_tensors = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "flat_gemm") == 0) {

@@ -35,6 +35,8 @@ SOURCES = {
     'conv_wino.hip': ['-fno-slp-vectorize'],
     'conv_wino4.hip': [],
     'conv_bf16.hip': [],
+    'conv_bf16t.hip': [],
+    'bf16_misc.hip': [],
     'rnn.hip': [],
     'rnn_persistent.hip': [],
     'pool.hip': [],

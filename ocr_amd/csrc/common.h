@@ -112,6 +112,7 @@ struct ConvLayer {
     int cout_pad = 0;       // cout rounded up to the kernel's N tile
     DevBuf w_f32;           // MFMA slab layout (see conv_mfma.hip) or direct layout (see conv_direct.hip)
     DevBuf w_bf16;          // bfloat16 slab of the same layer (see conv_bf16.hip), when cin % 16 == 0
+    DevBuf w_bf16t;         // bfloat16 LDS images per (output tile, chunk, tap) for the bfloat16-tensor kernels (see conv_bf16t.hip), when cin % 32 == 0
     DevBuf w_wino;          // 3x3 layers with >= 64 output channels: Winograd-transformed filters (see conv_wino.hip)
     DevBuf w_wino4;         // the same layers: F(4x4,3x3)-transformed filters (see conv_wino4.hip)
     DevBuf w_wino4c;        // of those, layers with a multiple of 128 output channels: the layout of its MODE 4
@@ -122,8 +123,9 @@ struct ConvLayer {
 };
 
 struct Activation {
-    const float* ptr = nullptr;
+    const void* ptr = nullptr;
     int64_t shape[4] = {0, 0, 0, 0};
+    bool bf16 = false;       // a bfloat16 tensor (the bfloat16-tensor path); read back as float32
 };
 
 struct EastNet {
@@ -156,6 +158,7 @@ struct CrnnNet {
     ConvLayer pred;          // 256 -> vocab
     DevBuf act[3];
     DevBuf feats, xw, hbuf, cbuf, seq, lin, logits, meta, lstm_counters;
+    DevBuf seq16;            // bfloat16-tensor path: output rows of a BiLSTM layer (R, 2H)
     DevBuf pmax, pidx;       // greedy decoding without logits: per row and block of 128 classes the maximum and its class
     static constexpr int kErrSlots = 16;
     static constexpr unsigned kErrPending = 0xFFFFFFFFu;
@@ -182,6 +185,7 @@ struct ocrhip_ctx {
     int wino4_split = 0;           // F(4x4,3x3) layers with >= 512 input channels: fused like the others (0), or transform once into `wino_ws` and multiply from it (1)
     ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
     int fuse_ctc = 1;              // tokens without a logits request: class layer reduced to per-block maxima in its epilogue (1) or logits written and re-read (0)
+    int bf16_tensors = 1;          // compute_dtype = OCRHIP_BF16: bfloat16 activations in HBM, tile kernels, bfloat16 recurrence (1); or the float32-tensor kernels with operands rounded on their way into LDS and a float32 recurrence (0)
     int flat_gemm = 1;             // 1x1 / 2x2 layers on the 256 x 128 flat GEMM (1) or on the implicit-GEMM convolution kernel (0)
     ocrhip::Profiler prof;
 };
@@ -207,6 +211,15 @@ int launch_conv_bf16(const ConvLayer& L, const float* x, float* y, int B, int H,
                      const float* up_src, int up_c, hipStream_t s, const float* residual);
 int compute_bf16();
 void set_compute_bf16(int on);
+
+// conv_bf16t.hip: bfloat16 tensors in HBM (the path of compute_dtype = OCRHIP_BF16 for the detector and the VGG
+// recogniser): 3x3 convolutions (optionally over `nin` inner images tiled side by side, `gap` zero columns apart) and
+// flat GEMMs (ks 1; ks 2 = 2x2 VALID convolution over (n, fh, fw, cin) images, rows = output pixels).
+int prepare_conv_bf16t(ConvLayer& L, const float* w_oihw, int cout, int cin, int ks);
+int launch_conv3_bf16t(const ConvLayer& L, const uint16_t* x, uint16_t* y, int B, int nin, int H, int Wc, int gap, int pool,
+                       bool relu, hipStream_t s);
+int launch_gemm_bf16t(const ConvLayer& L, const uint16_t* x, void* y, bool y_f32, int64_t M, int n, int fh, int fw, bool relu,
+                      hipStream_t s);
 
 // conv_wino.hip: the same 3x3 layers by Winograd F(2x2,3x3) (cout_pad % 64 == 0, cin % 8 == 0); launch_conv_mfma
 // forwards to it when the handle's "conv3x3_winograd" option is on (the default).
@@ -243,9 +256,17 @@ void set_flat_gemm(int on);
 
 // conv_direct.hip: first layers (Cin 3 or 1) and the 32->6 sigmoid heads.
 int prepare_conv_direct(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);
-int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y, int B, int H, int W, int pool,
-                      hipStream_t s);
+//   out_bf16: y is a bfloat16 tensor (the bfloat16-tensor path; matrix-core kernels only)
+int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, void* y, int B, int H, int W, int pool,
+                      hipStream_t s, bool out_bf16 = false);
 int launch_east_heads(const ConvLayer& L, const float* x, float* maps, int64_t npix, hipStream_t s);
+
+// bf16_misc.hip: bandwidth-bound pieces of the bfloat16-tensor path
+int launch_upcat16(const uint16_t* up, const uint16_t* res, uint16_t* out, int B, int H, int W, int up_c, int res_c, hipStream_t s);
+int launch_east_heads16(const ConvLayer& L, const uint16_t* x, float* maps, int64_t npix, hipStream_t s);
+int launch_mean_rows16(const uint16_t* x, uint16_t* y, int B, int H, int W, int C, hipStream_t s);
+int launch_f32_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t s);
+int launch_bf16_to_f32(const uint16_t* x, float* y, int64_t n, hipStream_t s);
 
 // decode.hip
 int launch_east_decode(ocrhip_ctx* h, const float* maps, int B, int mh, int mw, int in_h, int in_w, float thr,
@@ -296,6 +317,9 @@ constexpr int kLstmErrorWords = 16;
 int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, float* hbuf, float* cbuf,
                       float* out, int n, int T, int H, const int* seq_T, const int* seq_row0, const int* step_active,
                       unsigned* counters, hipStream_t s);
+int launch_lstm_layer16(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, uint16_t* hbuf16, float* cbuf,
+                        uint16_t* out16, int n, int T, int H, const int* seq_T, const int* seq_row0, const int* step_active,
+                        unsigned* counters, hipStream_t s);
 int lstm_debug_drop();               // test hook of the handle in use on this thread: withhold one hand-over (see ocrhip.h)
 void set_lstm_debug_drop(int on);
 int lstm_persistent();               // option of the handle in use on this thread

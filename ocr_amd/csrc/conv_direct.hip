@@ -195,10 +195,17 @@ __global__ __launch_bounds__(256) void conv_first_rows_kernel(const void* __rest
 // float32 like the vector kernel's, in pairs of k instead of one by one.
 typedef float floatx16_cf __attribute__((ext_vector_type(16)));
 
-template <bool U8>
+__device__ __forceinline__ unsigned cf_bf16_pair(float lo, float hi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// OUT16: the output tensor is bfloat16 (the bfloat16-tensor path): same sums, rounded once on the way out.
+template <bool U8, bool OUT16>
 __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const void* __restrict__ xin, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              const float* __restrict__ bias, void* __restrict__ yout,
                                                               int H, int W) {
+    float* y = reinterpret_cast<float*>(yout);
     constexpr int ROWS = 8, IW = 66, IN_FLOATS = (ROWS + 2) * IW * 3, TS = 72;
     __shared__ float s_in[IN_FLOATS + 4];
     __shared__ __attribute__((aligned(16))) float s_t[4][32 * TS];
@@ -257,7 +264,8 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const void* __rest
 
     // the workgroup's output rows start at the descriptor's base: one lane offset for all stores, the unit in the scalar offset
     const int64_t first = (((int64_t)b * H + oy0) * W + ox0) * 64;
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(y + first), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        OUT16 ? (void*)(reinterpret_cast<uint16_t*>(yout) + first) : (void*)(y + first), 0, 0x7fffffff, 0x00020000);
     float* t = s_t[wave];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -292,12 +300,26 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const void* __rest
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int npx = row_ok ? min(32, W - ox0 - h * 32) : 0;    // valid pixels of this half (<= 0: none)
+        if constexpr (OUT16) {
+            const int unit_off = (r * W + h * 32) * 128;           // bytes from the workgroup's first pixel
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = lane + 64 * j;                       // 16-byte piece within the unit: pixel i / 8, channel octet i % 8
+                const float4 q0 = *reinterpret_cast<const float4*>(&t[(i >> 3) * TS + (i & 7) * 8]);
+                const float4 q1 = *reinterpret_cast<const float4*>(&t[(i >> 3) * TS + (i & 7) * 8 + 4]);
+                const unsigned p0 = cf_bf16_pair(q0.x, q0.y), p1 = cf_bf16_pair(q0.z, q0.w), p2 = cf_bf16_pair(q1.x, q1.y), p3 = cf_bf16_pair(q1.z, q1.w);
+                buffer_store_b128_guarded(ocr_floatx4{__builtin_bit_cast(float, p0), __builtin_bit_cast(float, p1), __builtin_bit_cast(float, p2),
+                                                      __builtin_bit_cast(float, p3)},
+                                          y_rsrc, (i >> 3) < npx ? i * 16 : (int)0x80000000, unit_off);
+            }
+        } else {
         const int unit_off = (r * W + h * 32) * 256;               // bytes from the workgroup's first pixel
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int i = lane + 64 * j;                           // float4 index within the unit: pixel i / 16, channel quad i % 16
             const float4 q = *reinterpret_cast<const float4*>(&t[(i >> 4) * TS + (i & 15) * 4]);
             buffer_store_b128_guarded(ocr_floatx4{q.x, q.y, q.z, q.w}, y_rsrc, (i >> 4) < npx ? i * 16 : (int)0x80000000, unit_off);
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -314,9 +336,11 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const void* __rest
 // owns 8 pooled rows x 64 pooled columns of one image: its 18 x 130 input values go through LDS once.  Same products,
 // taps summed in the order of conv_first_kernel (the matrix instruction adds two per step), max and bias + ReLU in the
 // same order: bit-identical on gfx950, which the tests pin; the instruction's internal order does not guarantee it.
+template <bool OUT16>
 __global__ __launch_bounds__(256) void conv_first_pool_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                   const float* __restrict__ bias, float* __restrict__ y,
+                                                                   const float* __restrict__ bias, void* __restrict__ yout,
                                                                    int H, int W) {
+    float* y = reinterpret_cast<float*>(yout);
     constexpr int PR = 8, PC = 64;                     // pooled rows x columns of the workgroup
     constexpr int IH = 2 * PR + 2, IW = 2 * PC + 2;    // input rows x columns incl. the border
     __shared__ float s_in[IH * IW + 4];
@@ -376,12 +400,18 @@ __global__ __launch_bounds__(256) void conv_first_pool_mfma_kernel(const float* 
 #pragma unroll
         for (int st = 0; st < 5; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bw[st], acc, 0, 0, 0);
         float* dst = y + (((int64_t)b * Ho + yo) * Wo + xo) * 32 + i;
+        unsigned* dst16 = reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(yout) + (((int64_t)b * Ho + yo) * Wo + xo) * 32 + i);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float v = fmaxf(fmaxf(acc[4 * q], acc[4 * q + 1]), fmaxf(acc[4 * q + 2], acc[4 * q + 3]));
             v = fmaxf(v + bv, 0.0f);
             const int px = 2 * q + lh;                      // pooled pixel of the unit
-            if (xo + px < Wo) dst[px * 32] = v;
+            if constexpr (OUT16) {
+                const float other = __shfl_xor(v, 1);       // channel i ^ 1 of the same pixel: even lanes store the pair
+                if (xo + px < Wo && (i & 1) == 0) dst16[px * 16] = cf_bf16_pair(v, other);
+            } else {
+                if (xo + px < Wo) dst[px * 32] = v;
+            }
         }
     }
 }
@@ -431,8 +461,8 @@ int prepare_conv_direct(ConvLayer& L, const float* w_oihw, const float* bias, in
     return OCRHIP_OK;
 }
 
-int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y, int B, int H, int W, int pool,
-                      hipStream_t s) {
+int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, void* y, int B, int H, int W, int pool,
+                      hipStream_t s, bool out_bf16) {
     OCR_REQUIRE(L.direct && L.ks == 3, "conv_first: layer is not a direct 3x3 layer");
     OCR_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, "conv_first: bad sizes B=%d H=%d W=%d", B, H, W);
     const float* w = L.w_f32.as<float>();
@@ -440,29 +470,46 @@ int launch_conv_first(const ConvLayer& L, const void* x, bool x_is_u8, float* y,
     const double px = (double)B * H * W;
     ProfScope prof(L.cin == 3 ? "conv_first<3,64>" : (pool ? "conv_first<1,32,pool>" : "conv_first<1,32>"), 2.0 * 9 * L.cin * L.cout * px,
                    px * L.cin * (x_is_u8 ? 1.0 : 4.0) + 4.0 * px * L.cout / (pool ? 4.0 : 1.0), s);
+    if (out_bf16) {          // the bfloat16-tensor path: matrix-core kernels only
+        if (L.cin == 3 && L.cout == 64 && pool == 0 && (int64_t)8 * W * 256 < (1ll << 31)) {
+            dim3 grid((W + 63) / 64, (H + 7) / 8, B), block(256);
+            if (x_is_u8)
+                hipLaunchKernelGGL((conv_first_mfma_kernel<true, true>), grid, block, 0, s, x, w, bias, y, H, W);
+            else
+                hipLaunchKernelGGL((conv_first_mfma_kernel<false, true>), grid, block, 0, s, x, w, bias, y, H, W);
+        } else if (L.cin == 1 && L.cout == 32 && pool == 1 && !x_is_u8 && H % 2 == 0 && W % 2 == 0) {
+            dim3 grid((W / 2 + 63) / 64, (H / 2 + 7) / 8, B), block(256);
+            hipLaunchKernelGGL(conv_first_pool_mfma_kernel<true>, grid, block, 0, s, reinterpret_cast<const float*>(x), w, bias, y, H, W);
+        } else {
+            set_error("conv_first: no bfloat16-output kernel for cin=%d cout=%d pool=%d", L.cin, L.cout, pool);
+            return OCRHIP_EINVAL;
+        }
+        OCR_HIP_CHECK(hipGetLastError());
+        return OCRHIP_OK;
+    }
     if (L.cin == 3 && L.cout == 64 && pool == 0) {
         dim3 grid((W + 63) / 64, (H + 7) / 8, B), block(256);
         if (first_layer_mfma() && (int64_t)8 * W * 256 < (1ll << 31)) {
             if (x_is_u8)
-                hipLaunchKernelGGL(conv_first_mfma_kernel<true>, grid, block, 0, s, x, w, bias, y, H, W);
+                hipLaunchKernelGGL((conv_first_mfma_kernel<true, false>), grid, block, 0, s, x, w, bias, y, H, W);
             else
-                hipLaunchKernelGGL(conv_first_mfma_kernel<false>, grid, block, 0, s, x, w, bias, y, H, W);
+                hipLaunchKernelGGL((conv_first_mfma_kernel<false, false>), grid, block, 0, s, x, w, bias, y, H, W);
         } else if (x_is_u8)
-            hipLaunchKernelGGL((conv_first_rows_kernel<3, 64, true, 8>), grid, block, 0, s, x, w, bias, y, H, W);
+            hipLaunchKernelGGL((conv_first_rows_kernel<3, 64, true, 8>), grid, block, 0, s, x, w, bias, reinterpret_cast<float*>(y), H, W);
         else
-            hipLaunchKernelGGL((conv_first_rows_kernel<3, 64, false, 8>), grid, block, 0, s, x, w, bias, y, H, W);
+            hipLaunchKernelGGL((conv_first_rows_kernel<3, 64, false, 8>), grid, block, 0, s, x, w, bias, reinterpret_cast<float*>(y), H, W);
     } else if (L.cin == 1 && L.cout == 32 && pool == 1 && !x_is_u8) {
         OCR_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_first: pooled layer needs even H, W (got %dx%d)", H, W);
         if (first_layer_mfma()) {
             dim3 grid((W / 2 + 63) / 64, (H / 2 + 7) / 8, B), block(256);
-            hipLaunchKernelGGL(conv_first_pool_mfma_kernel, grid, block, 0, s, reinterpret_cast<const float*>(x), w, bias, y, H, W);
+            hipLaunchKernelGGL(conv_first_pool_mfma_kernel<false>, grid, block, 0, s, reinterpret_cast<const float*>(x), w, bias, y, H, W);
         } else {
             dim3 grid((W / 2 + 63) / 64, H / 2, B), block(256);
-            hipLaunchKernelGGL((conv_first_kernel<1, 32, true, false>), grid, block, 0, s, x, w, bias, y, H, W);
+            hipLaunchKernelGGL((conv_first_kernel<1, 32, true, false>), grid, block, 0, s, x, w, bias, reinterpret_cast<float*>(y), H, W);
         }
     } else if (L.cin == 1 && L.cout == 32 && pool == 0 && !x_is_u8) {
         dim3 grid((W + 63) / 64, H, B), block(256);
-        hipLaunchKernelGGL((conv_first_kernel<1, 32, false, false>), grid, block, 0, s, x, w, bias, y, H, W);
+        hipLaunchKernelGGL((conv_first_kernel<1, 32, false, false>), grid, block, 0, s, x, w, bias, reinterpret_cast<float*>(y), H, W);
     } else {
         set_error("conv_first: unsupported configuration cin=%d cout=%d pool=%d u8=%d", L.cin, L.cout, pool, (int)x_is_u8);
         return OCRHIP_EINVAL;

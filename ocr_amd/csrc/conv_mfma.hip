@@ -399,6 +399,7 @@ int prepare_conv_mfma(ConvLayer& L, const float* w_oihw, const float* bias, int 
     if (ks == 3 && BN == 64 && cin % 16 == 0) OCR_TRY(prepare_conv_wino(L, w_oihw, cout, cin));
     if (ks == 3 && BN == 64 && cin % 16 == 0) OCR_TRY(prepare_conv_wino4(L, w_oihw, cout, cin));
     if (cin % 16 == 0) OCR_TRY(prepare_conv_bf16(L, w_oihw, cout, cin, ks));
+    if (cin % 32 == 0) OCR_TRY(prepare_conv_bf16t(L, w_oihw, cout, cin, ks));
     if (ks != 3 && cin % 16 == 0) OCR_TRY(prepare_gemm_f32(L, w_oihw, bias, cout, cin, ks));
     return OCRHIP_OK;
 }

@@ -563,6 +563,197 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves_kernel(const LayerArg
     }
 }
 
+// ---- The independent-waves layer on bfloat16 operands (the bfloat16-tensor path, `compute_dtype = OCRHIP_BF16`).
+// Same structure, hand-over and cell arithmetic as lstm_layer_waves_kernel; what changes is the recurrent product:
+// h_{t-1} travels between workgroups as bfloat16 (half the hand-over bytes: 8 instead of 16 loads of 16 bytes per
+// lane and block, 4-byte stores of unit pairs), the workgroup's W_hh slice is converted to bfloat16 while its LDS image
+// is built (64 KB), and the product runs on v_mfma_f32_16x16x32_bf16: 64 matrix instructions of 16 cycles per block
+// and step where the float32 kernel issues 512 of 32.  Gate pre-activations (x W_ih + b, float32), the accumulation,
+// the cell state and the cell arithmetic stay float32; the layer's output rows are bfloat16 like every activation of
+// this path.
+typedef __bf16 bf16x8_l __attribute__((ext_vector_type(8)));
+typedef unsigned uintx4_l __attribute__((ext_vector_type(4)));
+
+struct LayerArgs16 {
+    const float* xw[2];      // per direction (R, 1024) float32, bias included; column = unit * 4 + gate
+    const float* whh[2];     // per direction (1024, 256) float32 as in the checkpoint
+    uint16_t* hbuf;          // (2 parities, 2 directions, n, 256) bfloat16
+    float* cbuf;             // (2 directions, n, 256)
+    uint16_t* out;           // (R, 512) bfloat16
+    const int* seq_T;
+    const int* seq_row0;
+    const int* step_active;
+    unsigned* counters;
+    unsigned* error;
+    int n, T, G;
+    int spin_cap;
+    int debug_drop;
+};
+
+__device__ __forceinline__ unsigned bf16_pair(float lo, float hi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+template <bool RAGGED>
+__global__ __launch_bounds__(512, 1) void lstm_layer_waves16_kernel(const LayerArgs16 a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    // [row R = 16 c + j: gate c & 3 of unit 16 (c >> 2) + j][32 slots of 16 bytes (8 k values), slot s stored at s ^ (R & 15)]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lg = lane >> 4;
+    const int G = a.G, n = a.n;
+
+    int sg, ub;
+    if ((2 * G) % 8 == 0) {
+        const int q = blockIdx.x & 7, r = blockIdx.x >> 3;
+        sg = q * (2 * G / 8) + (r >> 3);
+        ub = r & 7;
+    } else {
+        sg = blockIdx.x >> 3;
+        ub = blockIdx.x & 7;
+    }
+    const int dir = sg / G, g = sg % G;
+    const int u0 = ub * 32;
+    unsigned* counters = a.counters + sg * kMaxPass;
+
+    {
+        const float* W = a.whh[dir];
+        for (int f = tid; f < 128 * 32; f += 512) {
+            const int R = f >> 5, c = f & 31;
+            const int ct = R >> 4, j = R & 15;
+            const float* src = W + ((int64_t)(ct & 3) * kH + u0 + 16 * (ct >> 2) + j) * kH + c * 8;
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            *reinterpret_cast<uintx4_l*>(lds16 + (R * 32 + (c ^ (R & 15))) * 16) =
+                uintx4_l{bf16_pair(v0.x, v0.y), bf16_pair(v0.z, v0.w), bf16_pair(v1.x, v1.y), bf16_pair(v1.z, v1.w)};
+        }
+    }
+    __syncthreads();                 // the only barrier
+
+    const unsigned char* wrow = lds16 + l16 * 512;          // + ct * 16 * 512 + ((4 j + lg) ^ l16) * 16
+
+    for (int t = 0; t < a.T; ++t) {
+        const int n_act = RAGGED ? a.step_active[t] : n;
+        const int act_local = (n_act > g) ? (n_act - g + G - 1) / G : 0;
+        if (act_local == 0) break;
+        const int blocks_here = (act_local + kBlockRows - 1) / kBlockRows;
+        const uint16_t* hprev = a.hbuf + ((int64_t)((t + 1) & 1) * 2 + dir) * n * kH;
+        uint16_t* hnext = a.hbuf + ((int64_t)(t & 1) * 2 + dir) * n * kH;
+
+        for (int rb = wave; rb < blocks_here; rb += 8) {
+            const int rows_here = min(kBlockRows, act_local - rb * kBlockRows);
+            int sv[4], rowv[4];
+            float xwv[4][2][4], cpv[4][2];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int j = 4 * lg + v;
+                const int s = max(n - 1 - ((rb * kBlockRows + j) * G + g), 0);
+                sv[v] = (j < rows_here) ? s : -1;
+                int Ts, r0;
+                if (RAGGED) {
+                    Ts = a.seq_T[s];
+                    r0 = a.seq_row0[s];
+                } else {
+                    Ts = a.T;
+                    r0 = s * a.T;
+                }
+                rowv[v] = r0 + (dir ? (Ts - 1 - t) : t);
+            }
+            floatx4 acc[8];
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+            if (t > 0) {
+                const unsigned want = 8u * (unsigned)t;
+                int spins = 0;
+                bool gave_up = false;
+                while (__hip_atomic_load(counters + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    const bool partner_gave_up = (spins & 255) == 0 && __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (spins >= a.spin_cap || partner_gave_up) {
+                        gave_up = true;
+                        break;
+                    }
+                }
+                if (gave_up) {
+                    if (lane == 0) __hip_atomic_fetch_or(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+                asm volatile("" ::: "memory");
+                const int dA = (rb * kBlockRows + l16) * G + g;
+                // lane (row l16, k group lg) holds k = 32 j + 8 lg .. + 7 for j = 0..7: 16-byte device-scope loads
+                const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hprev, 0, n * (kH * 2), 0x00020000);
+                const int h_off = (l16 < rows_here) ? (max(n - 1 - dA, 0) * kH + lg * 8) * 2 : (int)0x80000000;
+                uintx4_l ha[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    ha[j] = __builtin_bit_cast(uintx4_l, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, h_off, 64 * j, kDeviceScope));
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu) {
+                        const int unit = u0 + 16 * uu + l16;
+                        const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
+                        xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
+                        cpv[v][uu] = a.cbuf[((int64_t)dir * n + max(sv[v], 0)) * kH + unit];
+                    }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bf16x8_l b8[8];
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) b8[ct] = *reinterpret_cast<const bf16x8_l*>(wrow + ct * (16 * 512) + (((4 * j + lg) ^ l16) * 16));
+                    const bf16x8_l av = __builtin_bit_cast(bf16x8_l, ha[j]);
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b8[ct], acc[ct], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu) {
+                        const int unit = u0 + 16 * uu + l16;
+                        const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
+                        xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
+                        cpv[v][uu] = 0.0f;
+                    }
+            }
+            // cell update: register v of column tile c = gate c & 3 of unit 16 (c >> 2) + l16, row 4 lg + v
+            unsigned hw[4];              // the lane's packed pair of h values per row: even lanes units (l16, l16 + 1), odd lanes units 16 + (l16 - 1, l16)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float hv[2];
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu) {
+                    float c;
+                    lstm_cell(xwv[v][uu][0] + acc[4 * uu + 0][v], xwv[v][uu][1] + acc[4 * uu + 1][v], xwv[v][uu][2] + acc[4 * uu + 2][v],
+                              xwv[v][uu][3] + acc[4 * uu + 3][v], cpv[v][uu], c, hv[uu]);
+                    cpv[v][uu] = c;
+                }
+                const float o0 = __shfl_xor(hv[0], 1), o1 = __shfl_xor(hv[1], 1);
+                hw[v] = (l16 & 1) ? bf16_pair(o1, hv[1]) : bf16_pair(hv[0], o0);
+            }
+            const int pair_unit = (l16 & 1) ? u0 + 16 + l16 - 1 : u0 + l16;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (sv[v] >= 0)
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(hnext + (int64_t)sv[v] * kH + pair_unit), hw[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the stores have reached the coherence point
+            const bool dropped = a.debug_drop && sg == 0 && ub == 7 && t == 0;
+            if (lane == 0 && !dropped) __hip_atomic_fetch_add(counters + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (sv[v] < 0) continue;
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu) a.cbuf[((int64_t)dir * n + sv[v]) * kH + u0 + 16 * uu + l16] = cpv[v][uu];
+                *reinterpret_cast<unsigned*>(a.out + (int64_t)rowv[v] * (2 * kH) + dir * kH + pair_unit) = hw[v];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // One bidirectional LSTM layer over n sequences in one launch of persistent workgroups.  `counters` must hold
@@ -646,6 +837,67 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
         hipLaunchKernelGGL(lstm_layer_kernel<true>, dim3(16 * a.G), dim3(256), kLdsBytes, s, a);
     else
         hipLaunchKernelGGL(lstm_layer_kernel<false>, dim3(16 * a.G), dim3(256), kLdsBytes, s, a);
+    OCR_HIP_CHECK(hipGetLastError());
+    OCR_HIP_CHECK(hipEventRecord(g_last_launch[dev], s));
+    return OCRHIP_OK;
+}
+
+// The same layer on bfloat16 operands (see lstm_layer_waves16_kernel): hbuf16 (2, 2, n, 256) and out16 (R, 512) are
+// bfloat16, xw and cbuf float32, whh the float32 checkpoint matrices (converted while the LDS image is built).
+// OCRHIP_ESTATE under the same conditions as launch_lstm_layer, and when the handle asks for one launch per step.
+int launch_lstm_layer16(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, uint16_t* hbuf16, float* cbuf,
+                        uint16_t* out16, int n, int T, int H, const int* seq_T, const int* seq_row0, const int* step_active,
+                        unsigned* counters, hipStream_t s) {
+    OCR_REQUIRE(xw_f && xw_b && whh_f && whh_b && hbuf16 && cbuf && out16 && counters, "lstm_layer16: null argument");
+    OCR_REQUIRE(n > 0 && T > 0, "lstm_layer16: bad sizes n=%d T=%d", n, T);
+    OCR_REQUIRE((seq_T == nullptr) == (seq_row0 == nullptr) && (seq_T == nullptr) == (step_active == nullptr),
+                "lstm_layer16: seq_T, seq_row0 and step_active go together");
+    if (H != kH || lstm_persistent() == 0) {
+        set_error("lstm_layer16: the persistent kernel is off or the model has %d hidden units (the per-step kernel runs instead)", H);
+        return OCRHIP_ESTATE;
+    }
+    int dev = 0;
+    OCR_HIP_CHECK(hipGetDevice(&dev));
+    OCR_REQUIRE(dev >= 0 && dev < kMaxDevices, "lstm_layer16: device index %d", dev);
+    std::lock_guard<std::mutex> lock(g_mutex);
+    static int max_groups16[kMaxDevices];
+    int& mg = max_groups16[dev];
+    constexpr int kLds16 = 128 * kH * 2;
+    if (mg == 0) {
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds16));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds16));
+        hipDeviceProp_t prop;
+        OCR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        int per_cu = 0;
+        OCR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<true>), 512, kLds16));
+        const int resident = per_cu * prop.multiProcessorCount;
+        mg = (resident >= 16) ? std::min(16, resident / 16) : -1;
+    }
+    if (mg < 0) {
+        set_error("lstm_layer16: the device cannot hold the persistent grid at once");
+        return OCRHIP_ESTATE;
+    }
+    LayerArgs16 a;
+    a.xw[0] = xw_f; a.xw[1] = xw_b; a.whh[0] = whh_f; a.whh[1] = whh_b;
+    a.hbuf = hbuf16; a.cbuf = cbuf; a.out = out16; a.seq_T = seq_T; a.seq_row0 = seq_row0; a.step_active = step_active;
+    a.counters = counters; a.error = counters + kLstmCounterCount; a.n = n; a.T = T;
+    a.debug_drop = lstm_debug_drop();
+    a.spin_cap = a.debug_drop ? (1 << 12) : (1 << 22);
+    a.G = std::max(1, std::min(mg, (n + 15) / 16));
+    const int blocks = ((n + a.G - 1) / a.G + kBlockRows - 1) / kBlockRows;
+    if (blocks > kMaxPass) {
+        set_error("lstm_layer16: more blocks per workgroup than counters (n=%d)", n);
+        return OCRHIP_ESTATE;
+    }
+    if (g_last_launch[dev])
+        OCR_HIP_CHECK(hipStreamWaitEvent(s, g_last_launch[dev], 0));
+    else
+        OCR_HIP_CHECK(hipEventCreateWithFlags(&g_last_launch[dev], hipEventDisableTiming));
+    OCR_HIP_CHECK(hipMemsetAsync(counters, 0, kLstmCounterCount * sizeof(unsigned), s));
+    if (seq_T)
+        hipLaunchKernelGGL(lstm_layer_waves16_kernel<true>, dim3(16 * a.G), dim3(512), kLds16, s, a);
+    else
+        hipLaunchKernelGGL(lstm_layer_waves16_kernel<false>, dim3(16 * a.G), dim3(512), kLds16, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     OCR_HIP_CHECK(hipEventRecord(g_last_launch[dev], s));
     return OCRHIP_OK;
