@@ -290,7 +290,7 @@ def main():
     # that kernel (its launches, live, for `roofline`); the per-stage breakdown of the other kernels comes from an
     # untimed pass behind the timed region.
     def is_matrix(st):
-        return st['flops'] > 0 and st['name'].startswith(('conv_mfma', 'conv_wino', 'conv_bf16', 'gemm_f32'))
+        return st['flops'] > 0 and st['name'].startswith(('conv_mfma', 'conv_wino', 'conv_bf16', 'gemm_f32', 'gemm_bf16t'))
 
     pipe.ctx.profile_enable(True)
     run(range(max(1, args.warmup)))
@@ -332,7 +332,7 @@ def main():
         # the executed flops are bounded by the MFMA peak
         wino_frac = 0.25 if dom['name'].startswith('conv_wino4') else (16.0 / 36.0 if dom['name'].startswith('conv_wino') else 1.0)
         executed = direct * wino_frac
-        peak = BF16_MFMA_PEAK_TFLOPS if dom['name'].startswith('conv_bf16') else F32_MFMA_PEAK_TFLOPS
+        peak = BF16_MFMA_PEAK_TFLOPS if dom['name'].startswith(('conv_bf16', 'gemm_bf16t')) else F32_MFMA_PEAK_TFLOPS
         gpu_ms = sum(s['total_ms'] for s in stats)
         conv_ms = sum(s['total_ms'] for s in mfma)
         conv_tflops = sum(s['flops'] for s in mfma) / (conv_ms * 1e-3) / 1e12
