@@ -331,6 +331,20 @@ int ocrhip_crnn_get_activation(ocrhip_handle h, const char* name, float* dst, in
 int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int V, const int* d_lengths,
                       int blank, int* d_tokens, float* d_scores, ocrhip_stream stream);
 
+/* CTC prefix beam search.  Replaces ctc_decode(method='beam_search') (utils/text/ctc_decoder.py:28-35 ->
+ * keras.ops.ctc_decode(strategy='beam_search', beam_width=num_beams, top_paths=1)), the default decoding of
+ * BaseOCR.infer (models/ocr/base_ocr.py:112-115,209-222): per-step log-softmax of the logits, blank / non-blank path
+ * probabilities in log space (float64), every label may extend every kept prefix, the num_beams most probable
+ * prefixes survive each step; the best prefix is returned with score = log p(prefix) / length.  One wave per sequence.
+ *   d_logits : device float32; d_row0 == NULL: (B,T,V) padded; else sequence b starts at row d_row0[b] of a flat
+ *              (sum of lengths, V) matrix (the layout ocrhip_crnn_forward_packed writes) and T is the row stride of
+ *              d_tokens (>= the longest sequence)
+ *   d_lengths: device (B) int32 or NULL (= T; required with d_row0);  num_beams: 1..16
+ *   d_tokens : device (B,T) int32 padded with -1;  d_scores: device (B) float32 */
+int ocrhip_ctc_beam_search(ocrhip_handle h, const float* d_logits, int B, int T, int V, const int* d_lengths,
+                           const int* d_row0, int blank, int num_beams, int* d_tokens, float* d_scores,
+                           ocrhip_stream stream);
+
 /* ------------------------------------------------------------------------------ stage timers --
  * Per-kernel device timing with HIP events recorded on the caller's stream around every launch the
  * library makes.  Replaces the hierarchical @timer / Timer instrumentation that wraps every stage of

@@ -60,6 +60,8 @@ SIGNATURES = {
     'ocrhip_crnn_get_activation': (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64)]),
     'ocrhip_ctc_greedy': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                   c_void_p]),
+    'ocrhip_ctc_beam_search': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                       c_void_p, c_void_p]),
     'ocrhip_profile_enable': (c_int, [c_void_p, c_int]),
     'ocrhip_profile_collect': (c_int, [c_void_p, ctypes.POINTER(KernelStat), c_int, ctypes.POINTER(c_int)]),
 }

@@ -332,6 +332,7 @@ int ocrhip_destroy(ocrhip_handle h) {
     if (h->crnn.lstm_err_host) (void)hipHostFree(h->crnn.lstm_err_host);
     h->decode_stage.release();
     h->lanms_ws.release();
+    h->beam_ws.release();
     h->wino_ws.release();
     ocrhip::set_current_workspace(nullptr);
     h->prof.recycle();
@@ -1137,6 +1138,12 @@ int ocrhip_ctc_greedy(ocrhip_handle h, const float* d_logits, int B, int T, int 
                       int* d_tokens, float* d_scores, ocrhip_stream stream) {
     OCR_HANDLE(h);
     return launch_ctc_greedy(d_logits, B, T, V, V, d_lengths, nullptr, blank, d_tokens, d_scores, (hipStream_t)stream);
+}
+
+int ocrhip_ctc_beam_search(ocrhip_handle h, const float* d_logits, int B, int T, int V, const int* d_lengths, const int* d_row0,
+                           int blank, int num_beams, int* d_tokens, float* d_scores, ocrhip_stream stream) {
+    OCR_HANDLE(h);
+    return launch_ctc_beam(h, d_logits, B, T, V, d_lengths, d_row0, blank, num_beams, d_tokens, d_scores, (hipStream_t)stream);
 }
 
 int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {

@@ -29,6 +29,7 @@ SOURCES = {
     'lanms.hip': ['-ffp-contract=off'],
     'crop.hip': ['-ffp-contract=off'],
     'ctc.hip': ['-ffp-contract=off'],
+    'ctc_beam.hip': ['-ffp-contract=off'],
     'conv_direct.hip': [],
     'conv_mfma.hip': [],
     'gemm_f32.hip': [],

@@ -168,6 +168,10 @@ struct CrnnNet {
     std::map<std::string, Activation> taps;
 };
 
+// ctc_beam.hip: CTC prefix beam search, one wave per sequence (row0 as for launch_ctc_greedy)
+int launch_ctc_beam(ocrhip_ctx* h, const float* logits, int B, int T, int V, const int* lengths, const int* row0, int blank,
+                    int num_beams, int* tokens, float* scores, hipStream_t s);
+
 }  // namespace ocrhip
 
 struct ocrhip_ctx {
@@ -176,6 +180,7 @@ struct ocrhip_ctx {
     ocrhip::CrnnNet crnn;
     ocrhip::DevBuf decode_stage;   // staging of the decode kernel
     ocrhip::DevBuf lanms_ws;       // scratch of the LANMS kernel
+    ocrhip::DevBuf beam_ws;        // prefix tree pools of the CTC beam search
     int lstm_debug_drop = 0;       // test hook: the persistent recurrence withholds one hand-over and times out quickly
     int lstm_persistent = 2;       // recurrence of a BiLSTM layer in one persistent launch: independent waves on blocks of 16 sequences where a workgroup has at least 8 blocks, workgroup-wide passes of 112 sequences otherwise (2), passes always (1), independent waves always (3); or one launch per step (0)
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
@@ -333,5 +338,9 @@ int launch_ctc_greedy(const float* logits, int B, int T, int V, int ld_v, const 
 // the same decoding from the (maximum, column) pairs per block of 128 columns that launch_gemm_f32_argmax writes
 int launch_ctc_greedy_partial(const float* pmax, const int* pidx, int n_blocks, int B, int T, const int* lengths,
                               const int* row0, int blank, int* tokens, float* scores, hipStream_t s);
+
+// ctc_beam.hip: CTC prefix beam search, one wave per sequence (row0 as for launch_ctc_greedy)
+int launch_ctc_beam(ocrhip_ctx* h, const float* logits, int B, int T, int V, const int* lengths, const int* row0, int blank,
+                    int num_beams, int* tokens, float* scores, hipStream_t s);
 
 }  // namespace ocrhip

@@ -330,6 +330,25 @@ class HipContext:
     def crnn_activation(self, name):
         return self._activation(self.lib.ocrhip_crnn_get_activation, name)
 
+    MAX_GPU_BEAMS = 16
+
+    def ctc_beam_search(self, logits, lengths=None, row0=None, t_stride=None, num_beams=10, blank=0):
+        """CTC prefix beam search on the GPU.  logits (B,T,V) float32 padded [+ lengths (B,) int32], or a flat
+        (sum T, V) matrix with lengths and row0 (B,) int32 (first row of each sequence) and t_stride >= max length
+        -> (tokens (B,T) int32 padded with -1, scores (B,) float32 = log p / length)."""
+        assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous()
+        if row0 is None:
+            B, T, V = logits.shape
+        else:
+            if lengths is None or t_stride is None:
+                raise ValueError('ctc_beam_search: a flat logits matrix needs lengths, row0 and t_stride')
+            B, T, V = int(lengths.shape[0]), int(t_stride), int(logits.shape[1])
+        tokens = torch.empty((B, T), dtype=torch.int32, device=logits.device)
+        scores = torch.empty((B,), dtype=torch.float32, device=logits.device)
+        check(self.lib.ocrhip_ctc_beam_search(self._h, _ptr(logits), B, T, V, _ptr(lengths), _ptr(row0), int(blank),
+                                              int(num_beams), _ptr(tokens), _ptr(scores), _stream()))
+        return tokens, scores
+
     def ctc_greedy(self, logits, lengths=None, blank=0):
         assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous()
         B, T, V = logits.shape

@@ -109,8 +109,9 @@ class BaseOCR:
     def recognise_rows(self, image, rows, method='greedy', num_beams=10, dezoom_factor=1.):
         """All rows of one image in one go -> (index of valid rows, texts, scores).
 
-        method 'greedy': argmax + collapse on the GPU.  method 'beam_search' / 'beam': the logits come
-        back to the host and go through CTC prefix beam search (utils/ctc_beam.py)."""
+        method 'greedy': argmax + collapse on the GPU.  method 'beam_search' / 'beam': CTC prefix beam search on
+        the GPU (one wave per row, ocrhip_ctc_beam_search) for up to 16 beams; wider beams go through the host
+        implementation of the same search (utils/ctc_beam.py)."""
         if method == 'beam':
             method = 'beam_search'
         if method not in ('greedy', 'beam_search'):
@@ -132,6 +133,14 @@ class BaseOCR:
         res = self.ctx.crnn_forward_packed(sorted_packed, widths, want_logits=(method == 'beam_search'))
         if method == 'greedy':
             toks, sc = res['tokens'].cpu().numpy(), res['scores'].cpu().numpy()
+            self.ctx.check_errors(synchronize=False)
+        elif 1 <= int(num_beams) <= self.ctx.MAX_GPU_BEAMS:
+            T = self.ctx.seq_len(widths).astype(np.int32)
+            row0 = (np.cumsum(T) - T).astype(np.int32)
+            dev = res['logits'].device
+            d_tok, d_sc = self.ctx.ctc_beam_search(res['logits'], torch.from_numpy(T).to(dev), torch.from_numpy(row0).to(dev),
+                                                   t_stride=int(T.max()), num_beams=int(num_beams), blank=self.blank_token_idx)
+            toks, sc = d_tok.cpu().numpy(), d_sc.cpu().numpy()
             self.ctx.check_errors(synchronize=False)
         else:
             from ...utils.ctc_beam import ctc_beam_search

@@ -1,12 +1,17 @@
 """Batched OCR pipeline on one GPU: pages in, boxes + strings out.
 
-Same stages and default arguments as `BaseOCR.infer(..., combine=False, method='greedy')` on top of
-`EAST.infer` in the reference (models/ocr/base_ocr.py:98-255, models/detection/base_detector.py:
-51-81, models/detection/east.py:64-95), but every stage runs once per batch of pages instead of
-once per image / once per text row:
+Same stages as `BaseOCR.infer` on top of `EAST.infer` in the reference (models/ocr/base_ocr.py:98-255,
+models/detection/base_detector.py:51-81, models/detection/east.py:64-95), but every stage runs once per
+batch of pages instead of once per image / once per text row:
 
-    EAST forward (B pages) -> RBOX decode -> LANMS + NMS -> [boxes to host: size arithmetic]
-    -> crop/resize/pack (all crops of all pages) -> CRNN + CTC greedy per padded width -> strings
+    EAST forward (B pages) -> RBOX decode -> LANMS + NMS -> [boxes to host: size arithmetic, grouping]
+    -> crop/resize/pack (all crops of all pages) -> CRNN -> CTC decoding on the GPU -> strings
+
+The default is the fast configuration `combine=False, method='greedy'` (one crop per detected word, greedy
+decoding fused into the class layer).  `combine=True, method='beam_search', num_beams=10` are the reference's own
+defaults (base_ocr.py:112-115,154-157): the words of a page are grouped into lines and paragraphs on the host
+(utils/combination.py), every LINE is one recogniser input, the texts of a paragraph are joined with ' \n', and the
+logits go through the CTC prefix beam search kernel.
 
 Only two small device->host copies per batch: the kept boxes (to compute crop sizes with the
 reference's float32/float64 host arithmetic) and the token ids.
@@ -22,13 +27,14 @@ import torch
 from ._lib import OcrHipError
 from .engine import HipContext, F32
 from .utils import image_sizes as S
+from .utils.combination import combine_boxes
 from .utils.text import CharTokenizer
 
 
 class OcrPipeline:
     def __init__(self, east_params, crnn_params, device=0, tokenizer=None, obj_threshold=0.35, nms_threshold=0.2,
                  merge_threshold=0.3, merge_method='union', max_crop_elems=1 << 20, ctx=None, compute_dtype=F32,
-                 rotated=False):
+                 rotated=False, combine=False, method='greedy', num_beams=10):
         self.ctx = ctx or HipContext(device)
         self.compute_dtype = compute_dtype          # F32 (the reference's precision) or BF16 operands with float32 accumulation
         self.device = self.ctx.device
@@ -43,6 +49,15 @@ class OcrPipeline:
         self.merge_method = merge_method
         self.max_crop_elems = max_crop_elems
         self.rotated = rotated
+        if method == 'beam':
+            method = 'beam_search'
+        if method not in ('greedy', 'beam_search'):
+            raise ValueError('Unknown CTC decoding method : {}'.format(method))
+        if method == 'beam_search' and not 1 <= int(num_beams) <= HipContext.MAX_GPU_BEAMS:
+            raise ValueError('num_beams must be 1..{} for the GPU beam search'.format(HipContext.MAX_GPU_BEAMS))
+        if combine and rotated:
+            raise ValueError('combine=True groups axis-aligned boxes; it does not go with rotated=True')
+        self.combine, self.method, self.num_beams = bool(combine), method, int(num_beams)
         self._rec_seq = 0              # recogniser calls enqueued so far
         self._failed_upto = -1         # calls up to this number were in flight when a persistent BiLSTM launch timed out
         self.lstm_fallbacks = 0        # batches recognised again with one launch per time step after such a time-out
@@ -103,7 +118,21 @@ class OcrPipeline:
             # the kernel reads 8 floats per crop where the axis-aligned one reads 4 integers: same buffer, bits kept
             rects = np.concatenate([p['geom'] for p in plans]).view(np.int32)
         else:
-            plans = [S.plan_crops(bx, H, W) for bx in per_image]
+            crop_boxes = per_image
+            if self.combine:
+                # words -> lines -> paragraphs (base_ocr.py:154-157); every line is one recogniser input
+                st['groups'] = []
+                crop_boxes = []
+                for bx in per_image:
+                    if len(bx):
+                        para, _, rows = combine_boxes(bx)
+                        rows = [np.asarray(r, dtype=np.float32).reshape(-1, 4) for r in rows]
+                    else:
+                        para, rows = bx, []
+                    owner = np.concatenate([np.full(len(r), i, dtype=np.int64) for i, r in enumerate(rows)]) if rows else np.zeros((0,), np.int64)
+                    st['groups'].append((np.asarray(para, dtype=np.float32).reshape(-1, 4), rows, owner))
+                    crop_boxes.append(np.concatenate(rows) if rows else np.zeros((0, 4), np.float32))
+            plans = [S.plan_crops(bx, H, W) for bx in crop_boxes]
             rects = np.concatenate([p['rects'] for p in plans])
         inter = np.concatenate([p['inter'] for p in plans])
         out_w = np.concatenate([p['out_w'] for p in plans])
@@ -119,7 +148,10 @@ class OcrPipeline:
         rects, inter, out_w, box_img, box_idx = rects[order], inter[order], out_w[order], box_img[order], box_idx[order]
         off = np.concatenate([[0], np.cumsum(64 * out_w.astype(np.int64))])
         dev = images.device
-        h_meta = torch.from_numpy(np.concatenate([rects.reshape(-1), inter.reshape(-1), out_w, box_img]).astype(np.int32)).pin_memory()
+        beam = self.method == 'beam_search'
+        seq_T = self.ctx.seq_len(out_w).astype(np.int32)
+        seq_row0 = (np.cumsum(seq_T) - seq_T).astype(np.int32)          # first row of each sequence in the flat logits
+        h_meta = torch.from_numpy(np.concatenate([rects.reshape(-1), inter.reshape(-1), out_w, box_img, seq_T, seq_row0]).astype(np.int32)).pin_memory()
         h_off = torch.from_numpy(off[:-1].astype(np.int64)).pin_memory()
         meta = h_meta.to(dev, non_blocking=True)
         d_off = h_off.to(dev, non_blocking=True)
@@ -131,7 +163,11 @@ class OcrPipeline:
                                                 int(off[-1]))
         else:
             packed = self.ctx.crop_resize_pack(images, d_rects, d_box_img, d_inter, d_out_w, d_off, int(off[-1]))
-        out = self.ctx.crnn_forward_packed(packed, out_w, compute_dtype=self.compute_dtype)
+        out = self.ctx.crnn_forward_packed(packed, out_w, want_logits=beam, compute_dtype=self.compute_dtype)
+        if beam:
+            d_T, d_row0 = meta[(r + 4) * n:(r + 5) * n], meta[(r + 5) * n:(r + 6) * n]
+            out['tokens'], out['scores'] = self.ctx.ctc_beam_search(out['logits'], d_T, d_row0, t_stride=int(seq_T.max()),
+                                                                    num_beams=self.num_beams, blank=self.tokenizer.blank_token_idx)
         st['seq'] = self._rec_seq
         self._rec_seq += 1
         st['out_w'] = out_w
@@ -149,10 +185,24 @@ class OcrPipeline:
         """Wait for the tokens and turn them into strings."""
         per_image = st['per_image']
         B = len(per_image)
+        if 'groups' in st:
+            return self._paragraph_strings(st)
         out = [{'boxes': per_image[b], 'texts': [''] * len(per_image[b]), 'scores': [None] * len(per_image[b]),
                 'valid': np.zeros(len(per_image[b]), dtype=bool)} for b in range(B)]
         if st['n'] == 0:
             return out
+        tokens, scores = self._wait_tokens(st)
+        box_img, box_idx = st['box_img'], st['box_idx']
+        texts = self.tokenizer.decode_batch(tokens[:st['n']])
+        for k, (b, i, text, score) in enumerate(zip(box_img.tolist(), box_idx.tolist(), texts, scores[:st['n']].tolist())):
+            o = out[b]
+            o['texts'][i] = text
+            o['scores'][i] = score
+            o['valid'][i] = True
+        return out
+
+    def _wait_tokens(self, st):
+        """Tokens and scores of a batch on the host, after the check (and, if needed, the repeat) of its recogniser."""
         st['tokens_ready'].synchronize()
         if st['seq'] > self._failed_upto:
             try:
@@ -166,14 +216,31 @@ class OcrPipeline:
                 self._failed_upto = self._rec_seq - 1
         if st['seq'] <= self._failed_upto:
             self._recognise_again(st)
-        tokens, scores = st['h_tokens'].numpy(), st['h_scores'].numpy()
-        box_img, box_idx = st['box_img'], st['box_idx']
+        return st['h_tokens'].numpy(), st['h_scores'].numpy()
+
+    def _paragraph_strings(self, st):
+        """combine=True: per page dict(boxes (P,4) paragraph boxes, rows [(k,4) line boxes], texts [lines joined with
+        ' \n'], scores [(k',) per valid line], valid (P,)): what BaseOCR.infer returns per entry of 'ocr'
+        (base_ocr.py:171-236); a paragraph none of whose lines gave a crop is not valid."""
+        out = []
+        for para, rows, _ in st['groups']:
+            out.append({'boxes': para, 'rows': rows, 'texts': [''] * len(para), 'scores': [np.zeros((0,), np.float32)] * len(para),
+                        'valid': np.zeros(len(para), dtype=bool)})
+        if st['n'] == 0:
+            return out
+        tokens, scores = self._wait_tokens(st)
         texts = self.tokenizer.decode_batch(tokens[:st['n']])
-        for k, (b, i, text, score) in enumerate(zip(box_img.tolist(), box_idx.tolist(), texts, scores[:st['n']].tolist())):
+        lines = [dict() for _ in out]               # page -> {line index: (text, score)}
+        for b, i, text, score in zip(st['box_img'].tolist(), st['box_idx'].tolist(), texts, scores[:st['n']].tolist()):
+            lines[b][i] = (text, score)
+        for b, (para, rows, owner) in enumerate(st['groups']):
             o = out[b]
-            o['texts'][i] = text
-            o['scores'][i] = score
-            o['valid'][i] = True
+            for p in range(len(para)):
+                mine = [lines[b][i] for i in np.nonzero(owner == p)[0].tolist() if i in lines[b]]
+                if mine:
+                    o['texts'][p] = ' \n'.join(t for t, _ in mine)
+                    o['scores'][p] = np.array([sc for _, sc in mine], dtype=np.float32)
+                    o['valid'][p] = True
         return out
 
     def _recognise_again(self, st):
@@ -182,7 +249,13 @@ class OcrPipeline:
         before = self.ctx.options.get('lstm_persistent', 2)
         self.ctx.set_option('lstm_persistent', 0)
         try:
-            out = self.ctx.crnn_forward_packed(packed, st['out_w'], compute_dtype=self.compute_dtype)
+            beam = self.method == 'beam_search'
+            out = self.ctx.crnn_forward_packed(packed, st['out_w'], want_logits=beam, compute_dtype=self.compute_dtype)
+            if beam:
+                n, r, meta = st['n'], st['_keep'][0].numel() // st['n'] - 6, st['_keep'][2]
+                out['tokens'], out['scores'] = self.ctx.ctc_beam_search(
+                    out['logits'], meta[(r + 4) * n:(r + 5) * n], meta[(r + 5) * n:(r + 6) * n], t_stride=int(out['tokens'].shape[1]),
+                    num_beams=self.num_beams, blank=self.tokenizer.blank_token_idx)
             st['h_tokens'].copy_(out['tokens'])
             st['h_scores'].copy_(out['scores'])
             self.ctx.check_errors(synchronize=True)
