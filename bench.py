@@ -59,6 +59,9 @@ def parse():
     ap.add_argument('--rotated', action='store_true',
                     help='opt-in path that keeps the quadrilaterals: rotated-IoU NMS + rotated crops (not the '
                          'reference behaviour; the CPU baseline is skipped)')
+    ap.add_argument('--reference-defaults', action='store_true',
+                    help="the reference's default arguments instead of the fast configuration: words grouped into lines and "
+                         "paragraphs (combine=True), CTC beam search with 10 beams (not the headline; the CPU baseline is skipped)")
     ap.add_argument('--resident', action='store_true',
                     help='pages already in HBM when the clock starts (no host -> device copy inside the timed region)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -202,7 +205,7 @@ def main():
     crnn_params = random_crnn_params(vocab_size=args.vocab, seed=2)
     from ocr_amd._lib import BF16, F32
     pipe = OcrPipeline(east_params, crnn_params, device=local_rank, compute_dtype=BF16 if args.dtype == 'bf16' else F32,
-                       rotated=args.rotated)
+                       rotated=args.rotated, **(dict(combine=True, method='beam_search', num_beams=10) if args.reference_defaults else {}))
 
     if args.share_gpu:
         pipe.ctx.set_option('lstm_persistent', 0)
@@ -355,6 +358,9 @@ def main():
             **({'rehearsal': '--share-gpu: all ranks on one GPU, not a scaling result'} if args.share_gpu else {}),
             **({'variant': '--rotated: rotated-IoU NMS + rotated crops, an opt-in extension, not the reference path'}
                if args.rotated else {}),
+            **({'variant': "--reference-defaults: BaseOCR.infer's default arguments (combine=True: one recogniser input per text "
+                           "line; method='beam_search', num_beams=10 on the GPU); `words_per_s` counts paragraphs"}
+               if args.reference_defaults else {}),
             'words_per_s': words / elapsed,
             'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'launches': dom['launches'],
                          'avg_ms': dom['total_ms'] / dom['launches'], 'achieved': executed,
@@ -377,7 +383,7 @@ def main():
                          'stages_tflops_direct_equiv': {s['name']: round(s['flops'] / (s['total_ms'] * 1e-3) / 1e12, 1)
                                                         for s in stats if s['flops'] > 0 and s['total_ms'] > 0}},
         }
-        if world == 1 and not args.no_cpu_baseline and args.vocab == 97 and not args.rotated:
+        if world == 1 and not args.no_cpu_baseline and args.vocab == 97 and not args.rotated and not args.reference_defaults:
             line['cpu_baseline'] = cpu_baseline(images, maps, east_params, crnn_params, min(args.cpu_pages, B))
         print(json.dumps(line), flush=True)
     pipe.ctx.close()

@@ -92,4 +92,4 @@ def test_reference_default_arguments_through_the_batched_pipeline():
     assert n_par >= 8 and streamed[1][0]['texts'] == got[0]['texts']
     # greedy through the same grouping: lines of a paragraph joined with ' \\n'
     g = OcrPipeline(None, None, ctx=pipe.ctx, combine=True)(d_img[:1], maps_override=d_maps[:1])[0]
-    assert [t.count(' \\n') + 1 for t, v in zip(g['texts'], g['valid']) if v] == [len(s) for s, v in zip(g['scores'], g['valid']) if v]
+    assert [t.count(' \n') + 1 for t, v in zip(g['texts'], g['valid']) if v] == [len(s) for s, v in zip(g['scores'], g['valid']) if v]
