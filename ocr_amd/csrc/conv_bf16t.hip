@@ -23,6 +23,7 @@
 //
 // Roofline: MFMA (dense bfloat16 peak 2.5 PFLOP/s); per step and workgroup 2 * 256 * BN * CK flop against
 // BN * CK * 2 bytes of weights from the L2 and 1/9 of a halo tile from HBM.
+#include <algorithm>
 #include <mutex>
 
 #include "common.h"
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(512) void conv_bf16t_kernel(const TileArgs a) {
     constexpr int KK = CK / 16;
     constexpr int SROW = BN * 2 + 16;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    constexpr int A_OFF = 0, B_OFF = 2 * A_BYTES;
+    constexpr int A_OFF = 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(512) void conv_bf16t_kernel(const TileArgs a) {
     const int tile_all = (int)(work / (unsigned)a.n_tiles_n);
     const int nChunks = (KS == 3 ? a.cin : a.row_bytes / 2) / CK;
     const int nSteps = nChunks * TAPS;
+    // a layer of one chunk needs one activation buffer: its workgroups take less LDS (the launcher sizes it) and two of
+    // them share a compute unit, one's prologue and epilogue behind the other's multiplications
+    const int B_OFF = (nChunks == 1 ? 1 : 2) * A_BYTES;
 
     int b = 0, y0 = 0, x0 = 0;
     long long m0 = 0;
@@ -247,6 +251,43 @@ __global__ __launch_bounds__(512) void conv_bf16t_kernel(const TileArgs a) {
     const int n0 = nt * BN;
     if constexpr (OUT_F32) {
         float* y = reinterpret_cast<float*>(a.y);
+        if ((a.cout & 3) == 0) {          // uniform
+            // float32 rows whose length is a multiple of 16 bytes: every wave passes its 32 rows x 64 channels through
+            // a staging area of its own (row stride 272 bytes: the lanes' 16-byte writes of a quad spread over the
+            // banks) and stores 256 contiguous bytes per row: whole 128-byte lines instead of 32-byte pieces
+            __builtin_amdgcn_s_barrier();          // every wave is done with the operand images
+            constexpr int FROW = 64 * 4 + 16;
+            unsigned char* mine = lds + wave * (32 * FROW);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cl = nb * 32 + 8 * j + 4 * h;
+                        const float4 bias = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 64 + cl);
+                        float4 o = make_float4(acc[mb][nb][4 * j] + bias.x, acc[mb][nb][4 * j + 1] + bias.y, acc[mb][nb][4 * j + 2] + bias.z,
+                                               acc[mb][nb][4 * j + 3] + bias.w);
+                        if (a.relu) { o.x = fmaxf(o.x, 0.0f); o.y = fmaxf(o.y, 0.0f); o.z = fmaxf(o.z, 0.0f); o.w = fmaxf(o.w, 0.0f); }
+                        *reinterpret_cast<float4*>(mine + r * FROW + cl * 4) = o;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const long long mrow = m0 + (wm * MB + mb) * 32;
+                const int cbase = n0 + wn * 64;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 4 + (lane >> 4), pc = lane & 15;
+                    const float4 v = *reinterpret_cast<const float4*>(mine + row * FROW + pc * 16);
+                    if (mrow + row < a.M && cbase + pc * 4 < a.cout) *reinterpret_cast<float4*>(y + (mrow + row) * a.cout + cbase + pc * 4) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            return;
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const long long m = m0 + (wm * MB + mb) * 32 + r;
@@ -264,13 +305,9 @@ __global__ __launch_bounds__(512) void conv_bf16t_kernel(const TileArgs a) {
                     }
                     if (m < a.M) {
                         float* dst = y + m * a.cout + co;
-                        if (co + 3 < a.cout && (a.cout & 3) == 0) {
-                            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                        } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (co + e < a.cout) dst[e] = o[e];
-                        }
+                        for (int e = 0; e < 4; ++e)
+                            if (co + e < a.cout) dst[e] = o[e];
                     }
                 }
         }
@@ -336,12 +373,13 @@ __global__ __launch_bounds__(512) void conv_bf16t_kernel(const TileArgs a) {
 }
 
 template <int KS, int CK, int BN>
-constexpr int lds_bytes() {
+constexpr int lds_bytes(bool one_chunk) {
     constexpr int ROWB = CK * 2, NP = ROWB / 16, PXI = 64 / NP;
     constexpr int NPA = KS == 3 ? 10 * 34 : 256;
     constexpr int A_BYTES = (NPA + PXI - 1) / PXI * 1024, B_BYTES = BN * ROWB;
-    constexpr int loop = 2 * A_BYTES + 2 * B_BYTES, stage = 256 * (BN * 2 + 16);
-    return loop > stage ? loop : stage;
+    const int loop = (one_chunk ? 1 : 2) * A_BYTES + 2 * B_BYTES;
+    constexpr int stage = 256 * (BN * 2 + 16), stage32 = 8 * 32 * (64 * 4 + 16);
+    return std::max(loop, std::max(stage, stage32));
 }
 
 std::mutex g_opt_in_mutex;
@@ -351,12 +389,14 @@ int launch_variant_t(const TileArgs& a, int64_t wgs, hipStream_t s) {
     static bool opted[64] = {};
     int dev = 0;
     OCR_HIP_CHECK(hipGetDevice(&dev));
-    constexpr int bytes = lds_bytes<KS, CK, BN>();
+    constexpr int bytes_max = lds_bytes<KS, CK, BN>(false);
+    const int n_chunks = (KS == 3 ? a.cin : a.row_bytes / 2) / CK;
+    const int bytes = lds_bytes<KS, CK, BN>(n_chunks == 1);
     {
         std::lock_guard<std::mutex> lock(g_opt_in_mutex);
         if (!opted[dev & 63]) {
             OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16t_kernel<KS, CK, BN, POOL, OUT_F32>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes_max));
             opted[dev & 63] = true;
         }
     }
