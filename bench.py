@@ -247,6 +247,13 @@ def main():
         from ocr_amd._lib import OcrHipError
         results = []
         ids = iter(batch_ids)
+        pending = []                # a batch taken while waiting for the queue to end: first of the next round
+
+        def next_id():
+            if pending:
+                return pending.pop()
+            # never wait for other ranks while batches are in flight here: they only complete when the feed moves on
+            return next(ids, None) if queue is None else queue.take(block=False)
         while True:
             inflight = []
 
@@ -255,7 +262,10 @@ def main():
                 if not args.resident:
                     copied.clear()
                     upload(0)
-                for i in ids:
+                while True:
+                    i = next_id()
+                    if i is None:
+                        return
                     inflight.append(i)
                     if args.resident:
                         yield d_img, d_maps
@@ -273,7 +283,6 @@ def main():
                         'texts': [t for o in out for t, v in zip(o['texts'], o['valid']) if v]}))
                     if queue is not None:
                         queue.done(i)
-                return results
             except OcrHipError as e:
                 if queue is None:
                     raise
@@ -282,6 +291,13 @@ def main():
                 for i in inflight:
                     retried.append(i)
                     queue.give_back(i)
+            if queue is None:
+                return results
+            # everything of this rank is done: now it may wait - for a batch another rank gives back, or for the end
+            i = queue.take(block=True)
+            if i is None:
+                return results
+            pending.append(i)
 
     def sync():
         torch.cuda.synchronize()
@@ -305,7 +321,7 @@ def main():
     pipe.ctx.profile_enable(True)
     sync()
     t0 = time.perf_counter()
-    local = run(iter(queue.take, None), queue)
+    local = run(None, queue)
     torch.cuda.synchronize()
     gathered = gather_results(local, n_batches, grp if dist is not None else None, dst=0)     # host gather, rank 0
     elapsed = time.perf_counter() - t0

@@ -130,7 +130,10 @@ class PageQueue:
     def _add(self, name, n):
         return int(self.store.add('%s/%s' % (self.key, name), n))
 
-    def take(self):
+    def take(self, block=True):
+        """The next item, or None.  block=True: None means every item of the queue is done (the call waits, polling the
+        list of returned items, while other ranks still work).  block=False: None also when nothing is to be had right
+        now - for a caller that must first finish what it has in flight (a software pipeline) before it may wait."""
         if self.store is None:
             if self._local < self.n_items:
                 i = self._local
@@ -160,7 +163,7 @@ class PageQueue:
                     continue
                 self.taken.append(i)
                 return i
-            if self._add('done', 0) >= self.n_items:
+            if self._add('done', 0) >= self.n_items or not block:
                 return None
             time.sleep(self.POLL_S)
 

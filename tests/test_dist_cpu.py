@@ -160,6 +160,58 @@ def test_a_failed_batch_goes_back_to_the_queue_and_another_rank_takes_it():
     assert ab0 and ab1
 
 
+def _pipelined_worker(rank, world, port, n_items, q):
+    """A consumer like the benchmark's: an item is finished two takes after it was taken (a software pipeline), so it
+    must never WAIT for the queue while items are in flight: non-blocking takes while it has work, one blocking take
+    when it has drained."""
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from ocr_amd import dist as D
+    grp = D.init_from_env(backend='gloo')
+    queue = D.PageQueue(n_items, grp)
+    grp.dist.barrier()
+    local, pending = [], []
+    while True:
+        inflight = []
+        while True:
+            i = pending.pop() if pending else queue.take(block=False)
+            if i is None:
+                break
+            inflight.append(i)
+            time.sleep(0.01 * (1 + rank))
+            if len(inflight) > 2:                     # the pipeline completes the oldest item
+                j = inflight.pop(0)
+                local.append((j, rank))
+                queue.done(j)
+        for j in inflight:                            # end of the feed: the pipeline drains
+            local.append((j, rank))
+            queue.done(j)
+        i = queue.take(block=True)
+        if i is None:
+            break
+        pending.append(i)
+    full = D.gather_results(local, n_items, grp, dst=0)
+    grp.dist.barrier()
+    q.put((rank, len(local), None if full is None else len(full)))
+    grp.dist.destroy_process_group()
+
+
+def test_pipelined_consumers_finish():
+    world, n_items = 2, 15
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] + got[1][1] == n_items and got[0][2] == n_items and got[1][2] is None
+
+
 def test_gather_results_rejects_lost_and_duplicate_items():
     import pytest
     from ocr_amd import dist as D
