@@ -246,7 +246,7 @@ def main():
         -> [(batch id, {'counts', 'boxes', 'texts'})]"""
         from ocr_amd._lib import OcrHipError
         results = []
-        ids = iter(batch_ids)
+        ids = iter(batch_ids) if batch_ids is not None else None
         pending = []                # a batch taken while waiting for the queue to end: first of the next round
 
         def next_id():
