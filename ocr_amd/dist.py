@@ -55,11 +55,31 @@ def _serve_store(addr, world, tries=16):
     raise RuntimeError('could not open a TCPStore on %s: %s' % (addr, last))
 
 
+class _stdout_to_stderr:
+    """The gloo transport announces its connections on the C-level stdout; a job whose stdout is a result line keeps
+    it clean by pointing file descriptor 1 at stderr while the process groups are being set up."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def init_from_env(backend=None, device=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when launched by torchrun.
     Returns a `Group` (unpacks as (rank, world, dist-or-None))."""
     if 'RANK' not in os.environ or 'WORLD_SIZE' not in os.environ:
         return Group()
+    with _stdout_to_stderr():
+        return _init_from_env(backend, device)
+
+
+def _init_from_env(backend, device):
     import torch.distributed as dist
     if not dist.is_initialized():
         if backend is None:

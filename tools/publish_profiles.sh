@@ -12,4 +12,10 @@ python tools/pmc_summary.py $P/fetch > profiles/$R/pmc_fetch_size.csv
 python tools/pmc_summary.py $P/write > profiles/$R/pmc_write_size.csv
 python tools/pmc_mfma.py $P/mfma > profiles/$R/pmc_mfma_util.csv
 if [ -d $P/issue ]; then python tools/pmc_issue.py $P/issue > profiles/$R/pmc_issue.csv; fi
+if [ -d $P/l2 ]; then python tools/pmc_l2.py $P/l2 > profiles/$R/pmc_l2_requests.csv; fi
+if [ -d $P/trace16 ]; then
+  cp $P/trace16/bench_kernel_stats.csv profiles/$R/bf16_bench_kernel_stats.csv
+  tail -1 $P/bench_bf16.json.log > profiles/$R/bf16_bench.json.log
+  python tools/pmc_mfma.py $P/mfma16 > profiles/$R/bf16_pmc_mfma_util.csv
+fi
 python tools/profile_report.py profiles/$R > profiles/$R/kernel_report.md
