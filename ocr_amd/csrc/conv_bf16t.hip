@@ -54,7 +54,6 @@ struct TileArgs {
     int fh, fw;                 // flat: row m is pixel (m / ((fh-1)(fw-1)), y, x) of (n, fh, fw, cin) images (2x2 VALID); fh = 0: row m starts at m * row_bytes
     int row_bytes;
     unsigned x_bytes;           // flat: bytes of x (offsets beyond it read as zeros)
-    int sched;                  // experiment: placement of the copy instructions inside a step
 };
 
 __device__ __forceinline__ int swz(int row, int np) {
@@ -87,10 +86,6 @@ __device__ __forceinline__ void copy_rows(__amdgpu_buffer_rsrc_t rsrc, unsigned 
         const int i = wave + 8 * k;
         if (i < ni) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + i * 1024), 16, src[k], soff, 0, 0);
     }
-}
-
-__device__ __forceinline__ void copy_row_one(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int src, int soff, int i, int ni) {
-    if (i < ni) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + i * 1024), 16, src, soff, 0, 0);
 }
 
 // KS: 3 = 3x3 convolution, padding 1; 1 = flat GEMM over rows (with row segments: 2x2 VALID convolutions).
@@ -224,13 +219,8 @@ __global__ __launch_bounds__(512) void conv_bf16t_kernel(const TileArgs a) {
             // my copies have landed; behind the barrier everybody's have, and everybody is done with step s - 1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const bool spread = a.sched != 0;
-            if (!spread || TAPS == 1) {
-                if (t == 0 && c + 1 < nChunks) copy_rows(x_rsrc, lds + A_OFF + ((c + 1) & 1) * A_BYTES, a_src, a_soff(c + 1), wave, NA_INSTR);
-            } else if (t < NAW && c + 1 < nChunks) {
-                copy_row_one(x_rsrc, lds + A_OFF + ((c + 1) & 1) * A_BYTES, a_src[t < NAW ? t : 0], a_soff(c + 1), wave + 8 * t, NA_INSTR);
-            }
-            if (!spread && s + 1 < nSteps) issue_b(s + 1, (s + 1) & 1);
+            if (t == 0 && c + 1 < nChunks) copy_rows(x_rsrc, lds + A_OFF + ((c + 1) & 1) * A_BYTES, a_src, a_soff(c + 1), wave, NA_INSTR);
+            if (s + 1 < nSteps) issue_b(s + 1, (s + 1) & 1);
             const int b_buf = B_OFF + (s & 1) * B_BYTES;
             const int tap_off = KS == 3 ? (t / 3) * HW + (t % 3) : 0;
             int x_base[MB];
@@ -252,17 +242,6 @@ __global__ __launch_bounds__(512) void conv_bf16t_kernel(const TileArgs a) {
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
-                if (spread && s + 1 < nSteps) {
-                    constexpr int NBW = (NB_INSTR + 7) / 8;
-#pragma unroll
-                    for (int k = 0; k < NBW; ++k) {
-                        const bool mine = a.sched == 1 ? (k % KK == kk) : (a.sched == 2 ? (kk == (wave < 4 ? 0 : KK / 2)) : kk == 0);
-                        const int i = wave + 8 * k;
-                        if (mine && i < NB_INSTR)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(lds + B_OFF + ((s + 1) & 1) * B_BYTES + i * 1024), 16,
-                                                                    lane * 16, (s + 1) * B_BYTES + i * 1024, 0, 0);
-                    }
-                }
             }
         }
     }
@@ -490,7 +469,6 @@ int launch_conv3_bf16t(const ConvLayer& L, const uint16_t* x, uint16_t* y, int B
     a.tiles_x = (int)((Wv + 31) / 32);
     a.tiles_per_image = a.tiles_x * ((H + 7) / 8);
     a.n_tiles_n = (L.cout + BN - 1) / BN;
-    { const char* e = getenv("OCRHIP_BF16T_SCHED"); a.sched = e ? atoi(e) : 0; }
     const int64_t wgs = (int64_t)a.tiles_per_image * a.n_tiles_n * B;
     OCR_REQUIRE(wgs < (1ll << 31), "conv3_bf16t: too many workgroups");
     char pname[64];
@@ -540,7 +518,6 @@ int launch_gemm_bf16t(const ConvLayer& L, const uint16_t* x, void* y, bool y_f32
     }
     a.tiles_x = 1; a.tiles_per_image = 1;
     a.n_tiles_n = (L.cout + BN - 1) / BN;
-    { const char* e = getenv("OCRHIP_BF16T_SCHED"); a.sched = e ? atoi(e) : 0; }
     const int64_t wgs = (M + 255) / 256 * a.n_tiles_n;
     OCR_REQUIRE(wgs < (1ll << 31), "gemm_bf16t: too many workgroups");
     char pname[64];
