@@ -90,6 +90,9 @@ __device__ __forceinline__ float4 load_h4(const float* p) {
     return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
                        __uint_as_float((unsigned)(hi >> 32)));
 }
+__device__ __forceinline__ float load_c(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 __device__ __forceinline__ void store_h(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -391,6 +394,143 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const LayerArgs a) {
 constexpr int kBlockRows = 16;
 constexpr int kDeviceScope = 16;    // cache policy bits of a buffer load: sc1 = device scope, what an agent-scope atomic load carries
 
+// One block (16 sequences) of one step for NU halves of the workgroup's 32 units, starting at half uh0: 4 NU accumulator
+// tiles.  `want`: what the block's counter reaches when all partners have published h_{t-1}.  False: the wait gave up.
+template <bool RAGGED, int NU>
+__device__ __forceinline__ bool waves_block(const LayerArgs& a, const float* Ws, int t, int rb, int uh0, int dir, int g, int u0,
+                                            int act_local, unsigned want, unsigned* counters, const float* hprev, float* hnext,
+                                            int lane, bool dropped) {
+    const int l16 = lane & 15, lg = lane >> 4;
+    const int G = a.G, n = a.n;
+    const float* wrow = Ws + l16 * 256;          // + ct * 16 * 256 + ((4 j + lg) ^ l16) * 4
+    const int rows_here = min(kBlockRows, act_local - rb * kBlockRows);
+    // the lane's elements: rows 4 lg + v (v = 0..3) of the block, unit l16 of each of the wave's unit halves
+    int sv[4], rowv[4];
+    float xwv[4][NU][4], cpv[4][NU];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int j = 4 * lg + v;
+        const int s = max(n - 1 - ((rb * kBlockRows + j) * G + g), 0);
+        sv[v] = (j < rows_here) ? s : -1;
+        int Ts, r0;
+        if (RAGGED) {
+            Ts = a.seq_T[s];
+            r0 = a.seq_row0[s];
+        } else {
+            Ts = a.T;
+            r0 = s * a.T;
+        }
+        rowv[v] = r0 + (dir ? (Ts - 1 - t) : t);
+    }
+    floatx4 acc[4 * NU];
+#pragma unroll
+    for (int ct = 0; ct < 4 * NU; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    if (t > 0) {
+        // wait until the partners have published this block of h_{t-1}
+        int spins = 0;
+        bool gave_up = false;
+        while (__hip_atomic_load(counters + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            const bool partner_gave_up = (spins & 255) == 0 && __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (spins >= a.spin_cap || partner_gave_up) {
+                gave_up = true;
+                break;
+            }
+        }
+        if (gave_up) {               // uniform in the wave: every lane read the same words
+            if (lane == 0) __hip_atomic_fetch_or(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;            // no barrier follows: the other waves run into the error word themselves
+        }
+        // the wave's 16 rows of h_{t-1}: lane (row l16, k group lg) holds k = 16 j + 4 lg .. + 3 for j = 0..15
+        asm volatile("" ::: "memory");          // the loads below stay behind the wait
+        const int dA = (rb * kBlockRows + l16) * G + g;
+        // 16-byte loads with device scope (the cache policy of the atomic loads above: served from where all
+        // XCDs agree), all 16 of a block in flight at once: at ~1.4 TB/s for the whole device these loads are
+        // bound by how many of them are outstanding, not by bandwidth.  Rows beyond the active ones carry an
+        // out-of-range offset and read as zeros.
+        const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hprev, 0, n * (kH * 4), 0x00020000);
+        const int h_off = (l16 < rows_here) ? (max(n - 1 - dA, 0) * kH + lg * 4) * 4 : (int)0x80000000;
+        float4 ha[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            ha[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, h_off, 64 * j, kDeviceScope));
+        // what the cell update needs besides the product, requested behind the h loads
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int uu = 0; uu < NU; ++uu) {
+                const int unit = u0 + 16 * (uh0 + uu) + l16;
+                const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
+                xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
+                cpv[v][uu] = load_c(a.cbuf + ((int64_t)dir * n + max(sv[v], 0)) * kH + unit);
+            }
+        const float* wmine = wrow + uh0 * (4 * 16 * 256);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            // W_hh operands of the step: the SIMD's other wave covers their latency
+            float4 b4[4 * NU];
+#pragma unroll
+            for (int ct = 0; ct < 4 * NU; ++ct) b4[ct] = *reinterpret_cast<const float4*>(wmine + ct * (16 * 256) + (((4 * j + lg) ^ l16) * 4));
+            const float4 av = ha[j];
+#pragma unroll
+            for (int ct = 0; ct < 4 * NU; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b4[ct].x, acc[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4 * NU; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b4[ct].y, acc[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4 * NU; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b4[ct].z, acc[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4 * NU; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b4[ct].w, acc[ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int uu = 0; uu < NU; ++uu) {
+                const int unit = u0 + 16 * (uh0 + uu) + l16;
+                const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
+                xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
+                cpv[v][uu] = 0.0f;
+            }
+    }
+    // cell update: register v of column tile c = gate c & 3 of unit 16 (c >> 2) + l16, row 4 lg + v
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int uu = 0; uu < NU; ++uu) {
+            float c, hval;
+            lstm_cell(xwv[v][uu][0] + acc[4 * uu + 0][v], xwv[v][uu][1] + acc[4 * uu + 1][v], xwv[v][uu][2] + acc[4 * uu + 2][v],
+                      xwv[v][uu][3] + acc[4 * uu + 3][v], cpv[v][uu], c, hval);
+            cpv[v][uu] = c;
+            xwv[v][uu][0] = hval;
+        }
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int uu = 0; uu < NU; ++uu)
+            if (sv[v] >= 0) store_h(hnext + (int64_t)sv[v] * kH + u0 + 16 * (uh0 + uu) + l16, xwv[v][uu][0]);
+    // the cell state goes out before the count as well, with the scope of h: the block may be another wave's at the next
+    // step (see the kernel)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int uu = 0; uu < NU; ++uu)
+            if (sv[v] >= 0) store_h(a.cbuf + ((int64_t)dir * n + sv[v]) * kH + u0 + 16 * (uh0 + uu) + l16, cpv[v][uu]);
+    // publish this part of h_t: the wave's stores have reached the coherence point, then its count
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+    if (lane == 0 && !dropped) __hip_atomic_fetch_add(counters + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int uu = 0; uu < NU; ++uu) {
+            if (sv[v] < 0) continue;
+            a.out[(int64_t)rowv[v] * (2 * kH) + dir * kH + u0 + 16 * (uh0 + uu) + l16] = xwv[v][uu][0];
+        }
+    return true;
+}
+
 template <bool RAGGED>
 __global__ __launch_bounds__(512, 1) void lstm_layer_waves_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -399,7 +539,6 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves_kernel(const LayerArg
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l16 = lane & 15, lg = lane >> 4;
     const int G = a.G, n = a.n;
 
     int sg, ub;
@@ -426,9 +565,13 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves_kernel(const LayerArg
     }
     __syncthreads();                 // the only barrier
 
-    // row j of block rb is the sequence of descending-length rank d = (rb * 16 + j) * G + g
-    const float* wrow = Ws + l16 * 256;          // + ct * 16 * 256 + ((4 j + lg) ^ l16) * 4
-
+    // row j of block rb is the sequence of descending-length rank d = (rb * 16 + j) * G + g.
+    // With 4 blocks or fewer left, a block is shared by two waves, 16 of the 32 units each: half the chain of matrix
+    // instructions per step when the step's latency is all there is.  Every workgroup of (direction, g) sees the same
+    // number of blocks, so all agree on the number of counts a step adds to a block's counter: `published` is what the
+    // counter of any block still running has reached when step t - 1 is complete (the running blocks are a prefix that
+    // only shrinks, so every block of step t has been through all steps before).
+    unsigned published = 0;
     for (int t = 0; t < a.T; ++t) {
         const int n_act = RAGGED ? a.step_active[t] : n;              // sequences still running, over all groups
         const int act_local = (n_act > g) ? (n_act - g + G - 1) / G : 0;      // prefix of this group's rows
@@ -436,129 +579,17 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves_kernel(const LayerArg
         const int blocks_here = (act_local + kBlockRows - 1) / kBlockRows;
         const float* hprev = a.hbuf + ((int64_t)((t + 1) & 1) * 2 + dir) * n * kH;
         float* hnext = a.hbuf + ((int64_t)(t & 1) * 2 + dir) * n * kH;
-
-        for (int rb = wave; rb < blocks_here; rb += 8) {
-            const int rows_here = min(kBlockRows, act_local - rb * kBlockRows);
-            // the lane's elements: rows 4 lg + v (v = 0..3) of the block, units l16 and 16 + l16 of the workgroup's 32
-            int sv[4], rowv[4];
-            float xwv[4][2][4], cpv[4][2];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int j = 4 * lg + v;
-                const int s = max(n - 1 - ((rb * kBlockRows + j) * G + g), 0);
-                sv[v] = (j < rows_here) ? s : -1;
-                int Ts, r0;
-                if (RAGGED) {
-                    Ts = a.seq_T[s];
-                    r0 = a.seq_row0[s];
-                } else {
-                    Ts = a.T;
-                    r0 = s * a.T;
-                }
-                rowv[v] = r0 + (dir ? (Ts - 1 - t) : t);
-            }
-            floatx4 acc[8];
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-            if (t > 0) {
-                // wait until the 8 workgroups of (direction, g) have published this block of h_{t-1}
-                const unsigned want = 8u * (unsigned)t;
-                int spins = 0;
-                bool gave_up = false;
-                while (__hip_atomic_load(counters + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    __builtin_amdgcn_s_sleep(1);
-                    ++spins;
-                    const bool partner_gave_up = (spins & 255) == 0 && __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    if (spins >= a.spin_cap || partner_gave_up) {
-                        gave_up = true;
-                        break;
-                    }
-                }
-                if (gave_up) {               // uniform in the wave: every lane read the same words
-                    if (lane == 0) __hip_atomic_fetch_or(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;                  // no barrier follows: the other waves run into the error word themselves
-                }
-                // the wave's 16 rows of h_{t-1}: lane (row l16, k group lg) holds k = 16 j + 4 lg .. + 3 for j = 0..15
-                asm volatile("" ::: "memory");          // the loads below stay behind the wait
-                const int dA = (rb * kBlockRows + l16) * G + g;
-                // 16-byte loads with device scope (the cache policy of the atomic loads above: served from where all
-                // XCDs agree), all 16 of a block in flight at once: at ~1.4 TB/s for the whole device these loads are
-                // bound by how many of them are outstanding, not by bandwidth.  Rows beyond the active ones carry an
-                // out-of-range offset and read as zeros.
-                const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hprev, 0, n * (kH * 4), 0x00020000);
-                const int h_off = (l16 < rows_here) ? (max(n - 1 - dA, 0) * kH + lg * 4) * 4 : (int)0x80000000;
-                float4 ha[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    ha[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, h_off, 64 * j, kDeviceScope));
-                // what the cell update needs besides the product, requested behind the h loads
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-#pragma unroll
-                    for (int uu = 0; uu < 2; ++uu) {
-                        const int unit = u0 + 16 * uu + l16;
-                        const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
-                        xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
-                        cpv[v][uu] = a.cbuf[((int64_t)dir * n + max(sv[v], 0)) * kH + unit];
-                    }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    // W_hh operands of the step: the SIMD's other wave covers their latency
-                    float4 b4[8];
-#pragma unroll
-                    for (int ct = 0; ct < 8; ++ct) b4[ct] = *reinterpret_cast<const float4*>(wrow + ct * (16 * 256) + (((4 * j + lg) ^ l16) * 4));
-                    const float4 av = ha[j];
-#pragma unroll
-                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b4[ct].x, acc[ct], 0, 0, 0);
-#pragma unroll
-                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b4[ct].y, acc[ct], 0, 0, 0);
-#pragma unroll
-                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b4[ct].z, acc[ct], 0, 0, 0);
-#pragma unroll
-                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b4[ct].w, acc[ct], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-#pragma unroll
-                    for (int uu = 0; uu < 2; ++uu) {
-                        const int unit = u0 + 16 * uu + l16;
-                        const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
-                        xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
-                        cpv[v][uu] = 0.0f;
-                    }
-            }
-            // cell update: register v of column tile c = gate c & 3 of unit 16 (c >> 2) + l16, row 4 lg + v
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int uu = 0; uu < 2; ++uu) {
-                    float c, hval;
-                    lstm_cell(xwv[v][uu][0] + acc[4 * uu + 0][v], xwv[v][uu][1] + acc[4 * uu + 1][v], xwv[v][uu][2] + acc[4 * uu + 2][v],
-                              xwv[v][uu][3] + acc[4 * uu + 3][v], cpv[v][uu], c, hval);
-                    cpv[v][uu] = c;
-                    xwv[v][uu][0] = hval;
-                }
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int uu = 0; uu < 2; ++uu)
-                    if (sv[v] >= 0) store_h(hnext + (int64_t)sv[v] * kH + u0 + 16 * uu + l16, xwv[v][uu][0]);
-            // publish this block of h_t: the wave's stores have reached the coherence point, then its count
-            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
-            const bool dropped = a.debug_drop && sg == 0 && ub == 7 && t == 0;
-            if (lane == 0 && !dropped) __hip_atomic_fetch_add(counters + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int uu = 0; uu < 2; ++uu) {
-                    if (sv[v] < 0) continue;
-                    const int unit = u0 + 16 * uu + l16;
-                    a.cbuf[((int64_t)dir * n + sv[v]) * kH + unit] = cpv[v][uu];
-                    a.out[(int64_t)rowv[v] * (2 * kH) + dir * kH + unit] = xwv[v][uu][0];
-                }
+        const bool dropped = a.debug_drop && sg == 0 && ub == 7 && t == 0;
+        if (blocks_here > 4) {
+            for (int rb = wave; rb < blocks_here; rb += 8)
+                if (!waves_block<RAGGED, 2>(a, Ws, t, rb, 0, dir, g, u0, act_local, published, counters, hprev, hnext, lane, dropped)) return;
+            published += 8u;
+        } else {
+            const int rb = wave >> 1;
+            if (rb < blocks_here &&
+                !waves_block<RAGGED, 1>(a, Ws, t, rb, wave & 1, dir, g, u0, act_local, published, counters, hprev, hnext, lane, dropped))
+                return;
+            published += 16u;
         }
     }
 }
