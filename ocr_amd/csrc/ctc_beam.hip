@@ -19,8 +19,9 @@
 //      of a pair is the number of pairs that precede it in the order (value descending, pair ascending), counted
 //      against all pairs at once: no selection rounds,
 //   4. ranks {stay, picked extension} entries the same way and keeps the num_beams first, in order.
-// Prefixes are nodes of a tree (parent, label) in a per-sequence pool in device memory; the kept ones are distinct,
-// so a (prefix, label) pair names at most one kept prefix.  Orders are total (value, then index): deterministic.
+// Prefixes are nodes of a tree (parent, label) in a per-sequence pool in device memory (read back for the answer only);
+// which prefix is which is decided by a hash of the labels, so a (prefix, label) pair names at most one kept prefix
+// even when that prefix had left the kept set and come back.  Orders are total (value, then index): deterministic.
 // Bound: latency of the longest sequence (a chain of ~1000 instructions per step), not bandwidth.
 #include "common.h"
 
@@ -44,6 +45,16 @@ __device__ __forceinline__ double logaddexp_d(double a, double b) {
     if (b == -INFINITY) return a;
     const double m = a > b ? a : b;
     return m + log1p(exp(-fabs(a - b)));
+}
+
+// A prefix is known by a 64-bit hash of its labels: the same labels give the same hash whichever tree node holds them.
+// (A prefix can leave the kept set while one of its extensions stays, and come back later as a new node; the extension
+// then still has to be recognised as its child.  Two different prefixes sharing a hash: 2^-64 per pair.)
+constexpr unsigned long long kRootHash = 0x243F6A8885A308D3ull;
+__device__ __forceinline__ unsigned long long extend_hash(unsigned long long h, int label) {
+    unsigned long long x = (h ^ (unsigned long long)(unsigned)(label + 1)) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29;
+    return x * 0xBF58476D1CE4E5B9ull + 0x632BE59BD9B4E019ull;
 }
 
 // wave arg-max in the order (value descending, index ascending); lanes without a candidate pass idx = INT_MAX
@@ -133,6 +144,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     // kept prefixes, in descending order of probability
     __shared__ double s_pb[kMaxBeams], s_pnb[kMaxBeams], s_total[kMaxBeams];
     __shared__ int s_node[kMaxBeams], s_parent[kMaxBeams], s_last[kMaxBeams];
+    __shared__ unsigned long long s_hash[kMaxBeams], s_phash[kMaxBeams];          // of the prefix, of the prefix without its last label
     // the step's labels
     __shared__ int s_top[kMaxTop];
     __shared__ double s_toplp[kMaxTop];
@@ -142,6 +154,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     // entries: stays [0, N), then picked extensions in the order of their rank
     __shared__ double e_b[kMaxEntries], e_nb[kMaxEntries], e_tot[kMaxEntries];
     __shared__ int e_node[kMaxEntries], e_parent[kMaxEntries], e_label[kMaxEntries];
+    __shared__ unsigned long long e_hash[kMaxEntries], e_phash[kMaxEntries];
     __shared__ unsigned s_newmask;
     __shared__ int s_count;
     __shared__ float s_rowl[2][128];          // the step's logits row (V <= 128), the next step's beside it
@@ -164,6 +177,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
                 if ((n + 1) * j <= K) { p_n[np] = n; p_j[np] = j; ++np; }          // ascending pair id n R + j
         s_count = np;
         s_pb[0] = 0.0; s_pnb[0] = -INFINITY; s_total[0] = 0.0; s_node[0] = 0; s_parent[0] = -1; s_last[0] = -1;
+        s_hash[0] = kRootHash; s_phash[0] = 0ull;
         nodes[0] = make_int2(-1, -1);
     }
     __syncthreads();
@@ -217,10 +231,11 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
         if (lane < N) {
             double nb = last >= 0 ? s_pnb[lane] + lp_last : -INFINITY;
             const int parent = s_parent[lane];
+            const unsigned long long phash = s_phash[lane];
             int from = -1;
-            if (parent >= 0)
+            if (last >= 0)
                 for (int n = 0; n < N; ++n)
-                    if (s_node[n] == parent) from = n;
+                    if (s_hash[n] == phash) from = n;
             if (from >= 0) {
                 const double val = ((last == s_last[from]) ? s_pb[from] : s_total[from]) + lp_last;
                 if (val != -INFINITY) nb = logaddexp_d(nb, val);
@@ -230,6 +245,8 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
             e_node[lane] = s_node[lane];
             e_parent[lane] = parent;
             e_label[lane] = last;
+            e_hash[lane] = s_hash[lane];
+            e_phash[lane] = phash;
         }
         if (lane == 0) s_newmask = 0u;
         __syncthreads();
@@ -257,13 +274,15 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
         bool new0 = lane < n_pairs && my_n0 < N && rank0 < K && v0 != -INFINITY;
         bool new1 = lane + 64 < n_pairs && my_n1 < N && rank1 < K && v1 != -INFINITY;
         if (new0) {
-            const int node_n = s_node[my_n0], c = s_top[my_j0];
-            for (int q = 0; q < N; ++q) new0 = new0 && !(s_parent[q] == node_n && s_last[q] == c);
+            const unsigned long long hash_n = s_hash[my_n0];
+            const int c = s_top[my_j0];
+            for (int q = 0; q < N; ++q) new0 = new0 && !(s_phash[q] == hash_n && s_last[q] == c);
             if (new0) atomicOr(&s_newmask, 1u << rank0);
         }
         if (new1) {
-            const int node_n = s_node[my_n1], c = s_top[my_j1];
-            for (int q = 0; q < N; ++q) new1 = new1 && !(s_parent[q] == node_n && s_last[q] == c);
+            const unsigned long long hash_n = s_hash[my_n1];
+            const int c = s_top[my_j1];
+            for (int q = 0; q < N; ++q) new1 = new1 && !(s_phash[q] == hash_n && s_last[q] == c);
             if (new1) atomicOr(&s_newmask, 1u << rank1);
         }
         __syncthreads();
@@ -271,10 +290,12 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
         if (new0) {
             const int e = N + __builtin_popcount(newmask & ((1u << rank0) - 1u));
             e_b[e] = -INFINITY; e_nb[e] = v0; e_node[e] = -1; e_parent[e] = s_node[my_n0]; e_label[e] = s_top[my_j0];
+            e_phash[e] = s_hash[my_n0]; e_hash[e] = extend_hash(s_hash[my_n0], s_top[my_j0]);
         }
         if (new1) {
             const int e = N + __builtin_popcount(newmask & ((1u << rank1) - 1u));
             e_b[e] = -INFINITY; e_nb[e] = v1; e_node[e] = -1; e_parent[e] = s_node[my_n1]; e_label[e] = s_top[my_j1];
+            e_phash[e] = s_hash[my_n1]; e_hash[e] = extend_hash(s_hash[my_n1], s_top[my_j1]);
         }
         const int ne = N + __builtin_popcount(newmask);
         __syncthreads();
@@ -297,6 +318,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
             }
             s_pb[rank] = e_b[lane]; s_pnb[rank] = e_nb[lane]; s_total[rank] = my;
             s_node[rank] = node; s_parent[rank] = parent; s_last[rank] = label;
+            s_hash[rank] = e_hash[lane]; s_phash[rank] = e_phash[lane];
         }
         next_node += K;
         N = newN;

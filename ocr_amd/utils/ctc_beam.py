@@ -49,13 +49,26 @@ def ctc_beam_search_one(logits, num_beams=10, blank=0):
         ext[:, blank] = _NEG
         # the extensions worth a dictionary entry: the num_beams most probable ones, and those that land on a kept prefix
         # (their probability adds to what that prefix keeps by staying)
+        # Ties are broken the way the GPU search breaks them (csrc/ctc_beam.hip), so that both give the same answer on
+        # any input: extensions in the order (value descending, prefix ascending, label rank ascending), the rank of a
+        # label being its place in the step's order (logit descending, label ascending).
         flat = ext.ravel()
         k = min(num_beams, flat.size)
-        picked = set(int(i) for i in np.argpartition(-flat, k - 1)[:k])
+        label_rank = np.empty(V, dtype=np.int64)
+        label_rank[np.lexsort((np.arange(V), -logits[t]))] = np.arange(V)
+        near = np.argpartition(-flat, k - 1)[:k]
+        cut = flat[near].min()
+        cand = np.nonzero(flat >= cut)[0]                    # everything that ties with the k-th value takes part
+        cand = cand[np.lexsort((label_rank[cand % V], cand // V, -flat[cand]))][:k]
+        picked = [int(i) for i in cand]
         index = {p: n for n, p in enumerate(prefixes)}
+        seen = set(picked)
         for p in prefixes:
             if p and p[:-1] in index:
-                picked.add(index[p[:-1]] * V + p[-1])
+                i = index[p[:-1]] * V + p[-1]
+                if i not in seen:
+                    picked.append(i)
+                    seen.add(i)
         nxt = {}
         for n, p in enumerate(prefixes):
             # stay on the prefix: a blank, or a repeat of its last label

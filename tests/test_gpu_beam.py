@@ -59,6 +59,33 @@ def test_beam_search_equals_the_host_search(ctx, V, T, kind, beams):
         ctx.ctc_beam_search(torch.from_numpy(x).cuda(), num_beams=17)
 
 
+def test_beam_search_ties_small_vocabularies_and_returning_prefixes(ctx):
+    """Randomised sweep with what random float logits never show: exact ties (logits on a coarse grid: the two searches
+    share one total order - value, then prefix, then label rank), vocabularies smaller than the beam, and prefixes that
+    leave the kept set while an extension of theirs stays and come back later (the extension must still be recognised
+    as their child: prefixes are compared by their labels, not by tree node)."""
+    from ocr_amd.utils.ctc_beam import ctc_beam_search
+    rng = np.random.default_rng(7)
+    for case in range(120):
+        V = int(rng.choice([2, 3, 5, 12, 64, 65, 97, 128, 129, 200]))
+        T, K, B = int(rng.integers(1, 40)), int(rng.integers(1, 17)), 6
+        x = rng.normal(0, 2, (B, T, V)).astype(np.float32)
+        if case % 4 == 1:
+            x = np.round(x * 2) / 2
+        elif case % 4 == 2:
+            x = np.round(x / 2).astype(np.float32)
+        elif case % 4 == 3:
+            lab = rng.integers(0, V, (B, T))
+            lab[:, 1::2] = lab[:, 0:-1:2][:, :lab[:, 1::2].shape[1]]
+            np.put_along_axis(x, lab[..., None], 8.0, axis=2)
+        lengths = rng.integers(0, T + 1, B).astype(np.int32)
+        lengths[0] = T
+        ref_t, ref_s = ctc_beam_search(x, lengths, num_beams=K, blank=0)
+        tok, sc = ctx.ctc_beam_search(torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda(), num_beams=K, blank=0)
+        np.testing.assert_array_equal(tok.cpu().numpy(), ref_t, err_msg='case %d V=%d T=%d K=%d' % (case, V, T, K))
+        np.testing.assert_allclose(sc.cpu().numpy(), ref_s, rtol=1e-5, atol=1e-6, err_msg='case %d' % case)
+
+
 def test_reference_default_arguments_through_the_batched_pipeline():
     """combine=True, method='beam_search', num_beams=10 (base_ocr.py:112-115,154-157): the batched pipeline returns,
     per page, the paragraphs BaseOCR.infer returns for that page alone - same grouping, same rows, same strings, scores
