@@ -80,6 +80,9 @@ int ocrhip_destroy(ocrhip_handle h);
  *   workgroups wait for each other, so launches of one process are chained (one at a time per device), and if another
  *   process or stream holds compute units for seconds a wait gives up, the kernel leaves, and the error surfaces through
  *   ocrhip_check_errors / the next ocrhip_crnn_forward* call on the handle (OCRHIP_EHIP, "lstm hand-over timed out").
+ *   "lstm16_units": 64 (default) | 32: hidden units a workgroup of the bfloat16 recurrence (compute_dtype OCRHIP_BF16)
+ *   keeps of W_hh in LDS.  Every workgroup reads all of h_{t-1} of its sequences, so 64 units (4 workgroups per sequence
+ *   group instead of 8) halve the hand-over reads; same results.
  *   "lstm_debug_drop_handover": test hook, 0 (default) | 1: one workgroup of the persistent recurrence withholds its
  *   first hand-over and waits give up after 4096 spins, which exercises the time-out path above.
  *   "wino4_split": 0 (default) runs every F(4x4,3x3) layer fused (a workgroup transforms its input tile itself); 1 runs

@@ -34,6 +34,9 @@ struct Bf16Scope {
 static thread_local int g_lstm_persistent = 2;
 int lstm_persistent() { return g_lstm_persistent; }
 void set_lstm_persistent(int on) { g_lstm_persistent = on; }
+static thread_local int g_lstm16_units = 64;
+int lstm16_units() { return g_lstm16_units; }
+void set_lstm16_units(int u) { g_lstm16_units = u; }
 static thread_local int g_lstm_debug_drop = 0;
 int lstm_debug_drop() { return g_lstm_debug_drop; }
 void set_lstm_debug_drop(int on) { g_lstm_debug_drop = on; }
@@ -270,6 +273,7 @@ using namespace ocrhip;
         ocrhip::set_current_profiler(&(h)->prof);                   \
         ocrhip::set_conv3x3_winograd((h)->conv3x3_winograd);        \
         ocrhip::set_lstm_persistent((h)->lstm_persistent);          \
+        ocrhip::set_lstm16_units((h)->lstm16_units);                \
         ocrhip::set_lstm_debug_drop((h)->lstm_debug_drop);          \
         ocrhip::set_flat_gemm((h)->flat_gemm);                      \
         ocrhip::g_fuse_ctc = (h)->fuse_ctc;                         \
@@ -1157,6 +1161,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "lstm_persistent") == 0) {
         OCR_REQUIRE(value >= 0 && value <= 3, "set_option: lstm_persistent is 0, 1, 2 or 3");
         h->lstm_persistent = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "lstm16_units") == 0) {
+        OCR_REQUIRE(value == 32 || value == 64, "set_option: lstm16_units is 32 or 64");
+        h->lstm16_units = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "lstm_debug_drop_handover") == 0) {

@@ -183,6 +183,7 @@ struct ocrhip_ctx {
     ocrhip::DevBuf beam_ws;        // prefix tree pools of the CTC beam search
     int lstm_debug_drop = 0;       // test hook: the persistent recurrence withholds one hand-over and times out quickly
     int lstm_persistent = 2;       // recurrence of a BiLSTM layer in one persistent launch: independent waves on blocks of 16 sequences where a workgroup has at least 8 blocks, workgroup-wide passes of 112 sequences otherwise (2), passes always (1), independent waves always (3); or one launch per step (0)
+    int lstm16_units = 64;         // bfloat16 recurrence: hidden units per workgroup (128 KB of W_hh in LDS, 4 workgroups share a sequence group) or 32
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     int first_layer_mfma = 1;      // the detector's 3 -> 64 first layer on the matrix cores (1) or on the vector ALU (0); identical results
     int wino4_wave_tiles = 2;      // fused F(4x4,3x3) layers: waves own whole (block, channel) tiles of 8 x 32 outputs, inverse transform in registers: workgroups of 4 waves x 16 channels, two per CU (1); the same, and workgroups of 8 waves x 16 channels where the layer has a multiple of 128 output channels (2); or the 3x3-component split with staged partial sums on 16 x 32 tiles (0)
@@ -317,7 +318,7 @@ int launch_lstm_step(const float* xw_f, const float* xw_b, const float* whh_f, c
 // counters: kLstmCounterCount unsigned ints cleared per launch, followed by kLstmErrorWords error words the kernel
 // sets when a hand-over between workgroups times out and the caller clears at the start of every forward).  OCRHIP_ESTATE when the hidden size is not 256, the device cannot
 // hold the grid at once or a workgroup would need more passes than it has counters (use the per-step kernel).
-constexpr int kLstmCounterCount = 2 * 16 * 64;
+constexpr int kLstmCounterCount = 2 * 32 * 64;
 constexpr int kLstmErrorWords = 16;
 int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, const float* whh_b, float* hbuf, float* cbuf,
                       float* out, int n, int T, int H, const int* seq_T, const int* seq_row0, const int* step_active,
@@ -329,6 +330,8 @@ int lstm_debug_drop();               // test hook of the handle in use on this t
 void set_lstm_debug_drop(int on);
 int lstm_persistent();               // option of the handle in use on this thread
 void set_lstm_persistent(int on);
+int lstm16_units();                  // hidden units per workgroup of the bfloat16 recurrence (32 or 64), option of the handle in use
+void set_lstm16_units(int u);
 
 // ctc.hip
 // row0 != nullptr: sequence b starts at row row0[b] of a flat (sum T, ld_v) logits matrix; T is then the

@@ -626,8 +626,11 @@ __device__ __forceinline__ unsigned bf16_pair(float lo, float hi) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
-template <bool RAGGED>
+// UW: hidden units of a workgroup, 32 or 64 (a 64 or 128 KB image of W_hh): 8 or 4 workgroups share a (direction, sequence
+// group) and every one of them reads all of h_{t-1} of its sequences, so 64 units halve the hand-over reads.
+template <bool RAGGED, int UW>
 __global__ __launch_bounds__(512, 1) void lstm_layer_waves16_kernel(const LayerArgs16 a) {
+    constexpr int NCT = UW / 4, NUU = UW / 16, PARTNERS = kH / UW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     // [row R = 16 c + j: gate c & 3 of unit 16 (c >> 2) + j][32 slots of 16 bytes (8 k values), slot s stored at s ^ (R & 15)]
 
@@ -640,19 +643,19 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves16_kernel(const LayerA
     int sg, ub;
     if ((2 * G) % 8 == 0) {
         const int q = blockIdx.x & 7, r = blockIdx.x >> 3;
-        sg = q * (2 * G / 8) + (r >> 3);
-        ub = r & 7;
+        sg = q * (2 * G / 8) + r / PARTNERS;
+        ub = r % PARTNERS;
     } else {
-        sg = blockIdx.x >> 3;
-        ub = blockIdx.x & 7;
+        sg = blockIdx.x / PARTNERS;
+        ub = blockIdx.x % PARTNERS;
     }
     const int dir = sg / G, g = sg % G;
-    const int u0 = ub * 32;
+    const int u0 = ub * UW;
     unsigned* counters = a.counters + sg * kMaxPass;
 
     {
         const float* W = a.whh[dir];
-        for (int f = tid; f < 128 * 32; f += 512) {
+        for (int f = tid; f < 4 * UW * 32; f += 512) {
             const int R = f >> 5, c = f & 31;
             const int ct = R >> 4, j = R & 15;
             const float* src = W + ((int64_t)(ct & 3) * kH + u0 + 16 * (ct >> 2) + j) * kH + c * 8;
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves16_kernel(const LayerA
         for (int rb = wave; rb < blocks_here; rb += 8) {
             const int rows_here = min(kBlockRows, act_local - rb * kBlockRows);
             int sv[4], rowv[4];
-            float xwv[4][2][4], cpv[4][2];
+            float xwv[4][NUU][4], cpv[4][NUU];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int j = 4 * lg + v;
@@ -692,12 +695,12 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves16_kernel(const LayerA
                 }
                 rowv[v] = r0 + (dir ? (Ts - 1 - t) : t);
             }
-            floatx4 acc[8];
+            floatx4 acc[NCT];
 #pragma unroll
-            for (int ct = 0; ct < 8; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
 
             if (t > 0) {
-                const unsigned want = 8u * (unsigned)t;
+                const unsigned want = (unsigned)PARTNERS * (unsigned)t;
                 int spins = 0;
                 bool gave_up = false;
                 while (__hip_atomic_load(counters + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves16_kernel(const LayerA
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
 #pragma unroll
-                    for (int uu = 0; uu < 2; ++uu) {
+                    for (int uu = 0; uu < NUU; ++uu) {
                         const int unit = u0 + 16 * uu + l16;
                         const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
                         xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
@@ -733,18 +736,22 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves16_kernel(const LayerA
                     }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    bf16x8_l b8[8];
-#pragma unroll
-                    for (int ct = 0; ct < 8; ++ct) b8[ct] = *reinterpret_cast<const bf16x8_l*>(wrow + ct * (16 * 512) + (((4 * j + lg) ^ l16) * 16));
                     const bf16x8_l av = __builtin_bit_cast(bf16x8_l, ha[j]);
 #pragma unroll
-                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b8[ct], acc[ct], 0, 0, 0);
+                    for (int c0 = 0; c0 < NCT; c0 += 8) {
+                        bf16x8_l b8[8];
+#pragma unroll
+                        for (int ct = 0; ct < 8; ++ct)
+                            b8[ct] = *reinterpret_cast<const bf16x8_l*>(wrow + (c0 + ct) * (16 * 512) + (((4 * j + lg) ^ l16) * 16));
+#pragma unroll
+                        for (int ct = 0; ct < 8; ++ct) acc[c0 + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b8[ct], acc[c0 + ct], 0, 0, 0);
+                    }
                 }
             } else {
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
 #pragma unroll
-                    for (int uu = 0; uu < 2; ++uu) {
+                    for (int uu = 0; uu < NUU; ++uu) {
                         const int unit = u0 + 16 * uu + l16;
                         const float4 xw4 = *reinterpret_cast<const float4*>(a.xw[dir] + (int64_t)rowv[v] * (4 * kH) + unit * 4);
                         xwv[v][uu][0] = xw4.x; xwv[v][uu][1] = xw4.y; xwv[v][uu][2] = xw4.z; xwv[v][uu][3] = xw4.w;
@@ -752,34 +759,42 @@ __global__ __launch_bounds__(512, 1) void lstm_layer_waves16_kernel(const LayerA
                     }
             }
             // cell update: register v of column tile c = gate c & 3 of unit 16 (c >> 2) + l16, row 4 lg + v
-            unsigned hw[4];              // the lane's packed pair of h values per row: even lanes units (l16, l16 + 1), odd lanes units 16 + (l16 - 1, l16)
+            unsigned hw[4][NUU / 2];     // the lane's packed pairs of h values per row: for unit sixteens (2p, 2p + 1), even lanes hold units 32 p + (l16, l16 + 1), odd lanes units 32 p + 16 + (l16 - 1, l16)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                float hv[2];
+                float hv[NUU];
 #pragma unroll
-                for (int uu = 0; uu < 2; ++uu) {
+                for (int uu = 0; uu < NUU; ++uu) {
                     float c;
                     lstm_cell(xwv[v][uu][0] + acc[4 * uu + 0][v], xwv[v][uu][1] + acc[4 * uu + 1][v], xwv[v][uu][2] + acc[4 * uu + 2][v],
                               xwv[v][uu][3] + acc[4 * uu + 3][v], cpv[v][uu], c, hv[uu]);
                     cpv[v][uu] = c;
                 }
-                const float o0 = __shfl_xor(hv[0], 1), o1 = __shfl_xor(hv[1], 1);
-                hw[v] = (l16 & 1) ? bf16_pair(o1, hv[1]) : bf16_pair(hv[0], o0);
+#pragma unroll
+                for (int pp = 0; pp < NUU / 2; ++pp) {
+                    const float o0 = __shfl_xor(hv[2 * pp], 1), o1 = __shfl_xor(hv[2 * pp + 1], 1);
+                    hw[v][pp] = (l16 & 1) ? bf16_pair(o1, hv[2 * pp + 1]) : bf16_pair(hv[2 * pp], o0);
+                }
             }
-            const int pair_unit = (l16 & 1) ? u0 + 16 + l16 - 1 : u0 + l16;
+            const int pair_unit = (l16 & 1) ? u0 + 16 + l16 - 1 : u0 + l16;          // + 32 p
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                if (sv[v] >= 0)
-                    __hip_atomic_store(reinterpret_cast<unsigned*>(hnext + (int64_t)sv[v] * kH + pair_unit), hw[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int pp = 0; pp < NUU / 2; ++pp)
+                    if (sv[v] >= 0)
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(hnext + (int64_t)sv[v] * kH + pair_unit + 32 * pp), hw[v][pp], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the stores have reached the coherence point
-            const bool dropped = a.debug_drop && sg == 0 && ub == 7 && t == 0;
+            const bool dropped = a.debug_drop && sg == 0 && ub == PARTNERS - 1 && t == 0;
             if (lane == 0 && !dropped) __hip_atomic_fetch_add(counters + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 if (sv[v] < 0) continue;
 #pragma unroll
-                for (int uu = 0; uu < 2; ++uu) a.cbuf[((int64_t)dir * n + sv[v]) * kH + u0 + 16 * uu + l16] = cpv[v][uu];
-                *reinterpret_cast<unsigned*>(a.out + (int64_t)rowv[v] * (2 * kH) + dir * kH + pair_unit) = hw[v];
+                for (int uu = 0; uu < NUU; ++uu) a.cbuf[((int64_t)dir * n + sv[v]) * kH + u0 + 16 * uu + l16] = cpv[v][uu];
+#pragma unroll
+                for (int pp = 0; pp < NUU / 2; ++pp)
+                    *reinterpret_cast<unsigned*>(a.out + (int64_t)rowv[v] * (2 * kH) + dir * kH + pair_unit + 32 * pp) = hw[v][pp];
             }
         }
     }
@@ -845,7 +860,7 @@ int launch_lstm_layer(const float* xw_f, const float* xw_b, const float* whh_f, 
         set_error("lstm_layer: more passes per workgroup than counters (n=%d)", n);
         return OCRHIP_ESTATE;
     }
-    static_assert(kLstmCounterCount == 2 * 16 * kMaxPass, "counter buffer size");
+    static_assert(kLstmCounterCount >= 2 * 16 * kMaxPass, "counter buffer size");
     // Two persistent grids on one device would each get part of the CUs and wait for workgroups that cannot start:
     // a launch waits for the persistent launch before it, whichever stream or handle of this process made it.
     if (g_last_launch[dev])
@@ -893,16 +908,20 @@ int launch_lstm_layer16(const float* xw_f, const float* xw_b, const float* whh_f
     std::lock_guard<std::mutex> lock(g_mutex);
     static int max_groups16[kMaxDevices];
     int& mg = max_groups16[dev];
-    constexpr int kLds16 = 128 * kH * 2;
+    // 64 units per workgroup (`lstm16_units`, default): a 128 KB image, 4 workgroups per (direction, group), up to 32 groups
+    const int UW = lstm16_units() == 32 ? 32 : 64;
+    const int partners = kH / UW;
+    const int kLds16 = 4 * UW * kH * 2;
     if (mg == 0) {
-        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds16));
-        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds16));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * kH * 2));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * kH * 2));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * kH * 2));
+        OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * kH * 2));
         hipDeviceProp_t prop;
         OCR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         int per_cu = 0;
-        OCR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<true>), 512, kLds16));
-        const int resident = per_cu * prop.multiProcessorCount;
-        mg = (resident >= 16) ? std::min(16, resident / 16) : -1;
+        OCR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_layer_waves16_kernel<true, 64>), 512, 256 * kH * 2));
+        mg = per_cu >= 1 ? prop.multiProcessorCount : -1;          // workgroups the device holds at once (one per CU counted)
     }
     if (mg < 0) {
         set_error("lstm_layer16: the device cannot hold the persistent grid at once");
@@ -914,7 +933,7 @@ int launch_lstm_layer16(const float* xw_f, const float* xw_b, const float* whh_f
     a.counters = counters; a.error = counters + kLstmCounterCount; a.n = n; a.T = T;
     a.debug_drop = lstm_debug_drop();
     a.spin_cap = a.debug_drop ? (1 << 12) : (1 << 22);
-    a.G = std::max(1, std::min(mg, (n + 15) / 16));
+    a.G = std::max(1, std::min(std::min(mg / (2 * partners), kLstmCounterCount / (2 * kMaxPass)), (n + 15) / 16));
     const int blocks = ((n + a.G - 1) / a.G + kBlockRows - 1) / kBlockRows;
     if (blocks > kMaxPass) {
         set_error("lstm_layer16: more blocks per workgroup than counters (n=%d)", n);
@@ -925,10 +944,16 @@ int launch_lstm_layer16(const float* xw_f, const float* xw_b, const float* whh_f
     else
         OCR_HIP_CHECK(hipEventCreateWithFlags(&g_last_launch[dev], hipEventDisableTiming));
     OCR_HIP_CHECK(hipMemsetAsync(counters, 0, kLstmCounterCount * sizeof(unsigned), s));
-    if (seq_T)
-        hipLaunchKernelGGL(lstm_layer_waves16_kernel<true>, dim3(16 * a.G), dim3(512), kLds16, s, a);
+    const dim3 grid(2 * partners * a.G);
+    if (UW == 64) {
+        if (seq_T)
+            hipLaunchKernelGGL((lstm_layer_waves16_kernel<true, 64>), grid, dim3(512), kLds16, s, a);
+        else
+            hipLaunchKernelGGL((lstm_layer_waves16_kernel<false, 64>), grid, dim3(512), kLds16, s, a);
+    } else if (seq_T)
+        hipLaunchKernelGGL((lstm_layer_waves16_kernel<true, 32>), grid, dim3(512), kLds16, s, a);
     else
-        hipLaunchKernelGGL(lstm_layer_waves16_kernel<false>, dim3(16 * a.G), dim3(512), kLds16, s, a);
+        hipLaunchKernelGGL((lstm_layer_waves16_kernel<false, 32>), grid, dim3(512), kLds16, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     OCR_HIP_CHECK(hipEventRecord(g_last_launch[dev], s));
     return OCRHIP_OK;
