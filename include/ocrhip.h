@@ -80,6 +80,9 @@ int ocrhip_destroy(ocrhip_handle h);
  *   workgroups wait for each other, so launches of one process are chained (one at a time per device), and if another
  *   process or stream holds compute units for seconds a wait gives up, the kernel leaves, and the error surfaces through
  *   ocrhip_check_errors / the next ocrhip_crnn_forward* call on the handle (OCRHIP_EHIP, "lstm hand-over timed out").
+ *   "bf16_fuse_first": 1 (default) | 0: the bfloat16-tensor detector computes its first layer (3 -> 64) inside the second
+ *   layer's kernel, per tile, from the page pixels (bfloat16 operands like every other layer of that path), so the
+ *   full-resolution 64-channel tensor is never written; 0 runs the float32 first-layer kernel and stores its result.
  *   "lstm16_units": 64 (default) | 32: hidden units a workgroup of the bfloat16 recurrence (compute_dtype OCRHIP_BF16)
  *   keeps of W_hh in LDS.  Every workgroup reads all of h_{t-1} of its sequences, so 64 units (4 workgroups per sequence
  *   group instead of 8) halve the hand-over reads; same results.

@@ -360,9 +360,10 @@ int ocrhip_east_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n
         const std::string conv = "extractor.features." + std::to_string(kEastVggIdx[i]);
         const std::string bn = "extractor.features." + std::to_string(kEastVggIdx[i] + 1);
         OCR_TRY(fold_conv_bn(W, conv, bn, true, kEastVggCout[i], cin, 3, wf, bf));
-        if (i == 0)
+        if (i == 0) {
             OCR_TRY(prepare_conv_direct(net.vgg[i], wf.data(), bf.data(), kEastVggCout[i], cin, 3));
-        else
+            OCR_TRY(prepare_first_pair_bf16t(net.vgg[i], wf.data()));
+        } else
             OCR_TRY(prepare_conv_mfma(net.vgg[i], wf.data(), bf.data(), kEastVggCout[i], cin, 3));
         cin = kEastVggCout[i];
     }
@@ -399,17 +400,29 @@ int ocrhip_east_load_weights(ocrhip_handle h, const ocrhip_tensor_desc* w, int n
 // The detector on bfloat16 tensors: the first layer and the heads compute in float32 (3 and 32 input channels are no
 // matrix work), every other layer is a bfloat16 tile kernel with float32 accumulation; activations are bfloat16 in HBM.
 // The x2 upsampling + concatenation of a merge stage is one bandwidth-bound pass in front of its 1x1 convolution.
-static int east_forward_bf16(EastNet& net, const void* d_img, int B, int H, int W, int in_dtype, float* d_maps, hipStream_t s) {
+static int east_forward_bf16(EastNet& net, const void* d_img, int B, int H, int W, int in_dtype, float* d_maps, bool fuse_first, hipStream_t s) {
     const size_t px = (size_t)B * H * W;
     unsigned char* act0 = net.act[0].as<unsigned char>();          // 256 bytes per input pixel
     uint16_t* T = reinterpret_cast<uint16_t*>(act0);               // upsample + concat of a merge stage: <= 24 bytes per input pixel
     uint16_t* X = reinterpret_cast<uint16_t*>(act0 + px * 64);     // <= 128 bytes per input pixel
     uint16_t* Y = net.act[1].as<uint16_t>();                       // 128 bytes per input pixel
     const int pool_c[5] = {64, 128, 256, 512, 512};
-    OCR_TRY(launch_conv_first(net.vgg[0], d_img, in_dtype == OCRHIP_U8, X, B, H, W, 0, s, true));
     const uint16_t* cur = X;
     int ch = H, cw = W, np = 0;
-    for (int i = 1; i < 13; ++i) {
+    int i0 = 1;
+    if (fuse_first && kEastVggPool[1] && (int64_t)H * W * 128 < (1ll << 31)) {
+        // layers 0 and 1 in one launch: the 64-channel tensor at full resolution is never written
+        uint16_t* dst = net.pool[0].as<uint16_t>();
+        OCR_TRY(launch_conv3_first_pair_bf16t(net.vgg[0], net.vgg[1], d_img, in_dtype == OCRHIP_U8, dst, B, H, W, s));
+        ch /= 2; cw /= 2;
+        record(net.taps, "pool1", dst, B, ch, cw, pool_c[0], true);
+        np = 1;
+        cur = dst;
+        i0 = 2;
+    } else {
+        OCR_TRY(launch_conv_first(net.vgg[0], d_img, in_dtype == OCRHIP_U8, X, B, H, W, 0, s, true));
+    }
+    for (int i = i0; i < 13; ++i) {
         uint16_t* dst = kEastVggPool[i] ? net.pool[np].as<uint16_t>() : ((cur == X) ? Y : X);
         OCR_TRY(launch_conv3_bf16t(net.vgg[i], cur, dst, B, 1, ch, cw, 0, kEastVggPool[i] ? 1 : 0, true, s));
         if (kEastVggPool[i]) {
@@ -469,7 +482,7 @@ int ocrhip_east_forward(ocrhip_handle h, const void* d_img, int B, int H, int W,
     float* A = net.act[0].as<float>();
     float* Bf = net.act[1].as<float>();
     net.taps.clear();
-    if (compute_dtype == OCRHIP_BF16 && h->bf16_tensors) return east_forward_bf16(net, d_img, B, H, W, in_dtype, d_maps, s);
+    if (compute_dtype == OCRHIP_BF16 && h->bf16_tensors) return east_forward_bf16(net, d_img, B, H, W, in_dtype, d_maps, h->bf16_fuse_first != 0, s);
 
     // VGG16-BN body; a convolution followed by 'M' writes the pooled tensor directly
     OCR_TRY(launch_conv_first(net.vgg[0], d_img, in_dtype == OCRHIP_U8, A, B, H, W, 0, s));
@@ -1161,6 +1174,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "lstm_persistent") == 0) {
         OCR_REQUIRE(value >= 0 && value <= 3, "set_option: lstm_persistent is 0, 1, 2 or 3");
         h->lstm_persistent = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "bf16_fuse_first") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: bf16_fuse_first is 0 or 1");
+        h->bf16_fuse_first = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "lstm16_units") == 0) {

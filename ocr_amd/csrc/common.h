@@ -183,6 +183,7 @@ struct ocrhip_ctx {
     ocrhip::DevBuf beam_ws;        // prefix tree pools of the CTC beam search
     int lstm_debug_drop = 0;       // test hook: the persistent recurrence withholds one hand-over and times out quickly
     int lstm_persistent = 2;       // recurrence of a BiLSTM layer in one persistent launch: independent waves on blocks of 16 sequences where a workgroup has at least 8 blocks, workgroup-wide passes of 112 sequences otherwise (2), passes always (1), independent waves always (3); or one launch per step (0)
+    int bf16_fuse_first = 1;       // bfloat16-tensor detector: the first two layers (3 -> 64, 64 -> 64 + pool) in one launch
     int lstm16_units = 64;         // bfloat16 recurrence: hidden units per workgroup (128 KB of W_hh in LDS, 4 workgroups share a sequence group) or 32
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     int first_layer_mfma = 1;      // the detector's 3 -> 64 first layer on the matrix cores (1) or on the vector ALU (0); identical results
@@ -222,6 +223,9 @@ void set_compute_bf16(int on);
 // recogniser): 3x3 convolutions (optionally over `nin` inner images tiled side by side, `gap` zero columns apart) and
 // flat GEMMs (ks 1; ks 2 = 2x2 VALID convolution over (n, fh, fw, cin) images, rows = output pixels).
 int prepare_conv_bf16t(ConvLayer& L, const float* w_oihw, int cout, int cin, int ks);
+int prepare_first_pair_bf16t(ConvLayer& first, const float* w_oihw);
+int launch_conv3_first_pair_bf16t(const ConvLayer& first, const ConvLayer& L, const void* page, bool page_u8, uint16_t* y, int B, int H,
+                                  int W, hipStream_t s);
 int launch_conv3_bf16t(const ConvLayer& L, const uint16_t* x, uint16_t* y, int B, int nin, int H, int Wc, int gap, int pool,
                        bool relu, hipStream_t s);
 int launch_gemm_bf16t(const ConvLayer& L, const uint16_t* x, void* y, bool y_f32, int64_t M, int n, int fh, int fw, bool relu,

@@ -54,6 +54,11 @@ struct TileArgs {
     int fh, fw;                 // flat: row m is pixel (m / ((fh-1)(fw-1)), y, x) of (n, fh, fw, cin) images (2x2 VALID); fh = 0: row m starts at m * row_bytes
     int row_bytes;
     unsigned x_bytes;           // flat: bytes of x (offsets beyond it read as zeros)
+    // FIRST: the layer in front (3 -> 64, ReLU) is computed into the activation image from the page itself
+    const void* page;           // (B, H, W, 3) uint8 or float32 (normalised)
+    const void* w1;             // bfloat16 fragments of the first layer's weights, see prepare_first_pair_bf16t
+    const float* b1;            // 64 floats
+    int page_u8;
 };
 
 __device__ __forceinline__ int swz(int row, int np) {
@@ -79,6 +84,7 @@ __device__ __forceinline__ uintx4 max8(uintx4 p, uintx4 q) {
 // One activation image: instruction i of `ni` (1 KB each) is issued by wave i % 8 with that wave's k-th source offset.
 // (No template parameter may reach the arguments of the LDS-destination load: the host pass of the compiler re-checks a
 // dependent call against the host's target features and silently drops the kernel's launch stub.)
+constexpr int kPatchBytes = 12 * 36 * 3 * 2 + 32 + 256;    // FIRST: the page pixels under a tile, bfloat16 (2592 bytes), and the first layer's bias
 constexpr int kMaxAW = 6;
 __device__ __forceinline__ void copy_rows(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, const int (&src)[kMaxAW], int soff, int wave, int ni) {
 #pragma unroll
@@ -90,7 +96,13 @@ __device__ __forceinline__ void copy_rows(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 
 // KS: 3 = 3x3 convolution, padding 1; 1 = flat GEMM over rows (with row segments: 2x2 VALID convolutions).
 // POOL (KS 3): 0 none, 1 max 2x2, 2 max over row pairs.  OUT_F32 (KS 1): float32 output rows instead of bfloat16.
-template <int KS, int CK, int BN, int POOL, bool OUT_F32>
+// FIRST (KS 3, one chunk of 64 channels): the input tensor is the output of the detector's first layer (3 -> 64 + ReLU,
+// architectures/east_arch.py:114-118), and instead of copying its halo tile from memory the workgroup computes it: the
+// 12 x 36 x 3 page pixels under the tile go to LDS as bfloat16, every wave multiplies 32 halo pixels x 32 (27 + zeros)
+// by the 32 x 64 weights with four matrix instructions and writes bias + ReLU of the result, rounded to bfloat16,
+// straight into the activation image (zeros where the halo pixel lies outside the picture: the padding of THIS layer).
+// The 64-channel tensor at full resolution - 128 bytes per pixel written and read back with halo - never exists.
+template <int KS, int CK, int BN, int POOL, bool OUT_F32, bool FIRST = false>
 __global__ __launch_bounds__(512) void conv_bf16t_kernel(const TileArgs a) {
     constexpr int TAPS = KS == 3 ? 9 : 1;
     constexpr int ROWB = CK * 2, NP = ROWB / 16, PXI = 64 / NP;
@@ -209,8 +221,80 @@ __global__ __launch_bounds__(512) void conv_bf16t_kernel(const TileArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[mb][nb][v] = 0.0f;
 
-    copy_rows(x_rsrc, lds + A_OFF, a_src, a_soff(0), wave, NA_INSTR);
-    issue_b(0, 0);
+    if constexpr (FIRST) {
+        static_assert(KS == 3 && CK == 64 && !OUT_F32, "fused first layer");
+        issue_b(0, 0);
+        constexpr int PW = TW + 4, PH = TH + 4, PN = PH * PW * 3;
+        // the first layer's weights as the row operand (prepared in that order: fragment (nb, kk) of lane l at
+        // ((nb * 2 + kk) * 64 + l) * 16 bytes; channel nb * 32 + r, k = kk * 16 + h * 8 + e, zero for k >= 27) and its bias,
+        // requested before the page pixels: one memory round trip for all three
+        bf16x8 w1f[2][2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                w1f[nb][kk] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(a.w1) + ((nb * 2 + kk) * 64 + lane) * 16);
+        uint16_t* patch = reinterpret_cast<uint16_t*>(lds + B_OFF + 2 * B_BYTES);
+        float* b1s = reinterpret_cast<float*>(lds + B_OFF + 2 * B_BYTES + kPatchBytes - 256);          // the bias, 64 floats
+        if (tid < 64) b1s[tid] = a.b1[tid];
+        for (int e = tid; e < PN; e += 512) {
+            const int pr = e / (PW * 3), rem = e - pr * (PW * 3);
+            const int gy = y0 - 2 + pr, gx = x0 - 2 + rem / 3;
+            float v = 0.0f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.Wc) {
+                const long long idx = (((long long)b * a.H + gy) * a.Wc + gx) * 3 + rem % 3;
+                v = a.page_u8 ? ((((float)reinterpret_cast<const uint8_t*>(a.page)[idx]) / 255.0f) - 0.5f) / 0.5f
+                              : reinterpret_cast<const float*>(a.page)[idx];
+            }
+            patch[e] = (uint16_t)bf16_bits(v);
+        }
+        __syncthreads();
+        for (int mt = wave; mt * 32 < NPA; mt += 8) {
+            const int p = mt * 32 + r;
+            const int pc = min(p, NPA - 1);
+            const int py = pc / HW, pxx = pc - py * HW;
+            const int base = (py * PW + pxx) * 3;
+            floatx16 f[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) f[nb][v] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 xf1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k0 = min(kk * 16 + e, 26), k1 = min(kk * 16 + 8 + e, 26);          // lane half 0 / 1
+                    const int off = h ? (k1 / 9) * (PW * 3) + k1 % 9 : (k0 / 9) * (PW * 3) + k0 % 9;
+                    xf1[e] = __builtin_bit_cast(__bf16, patch[base + off]);
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) f[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[nb][kk], xf1, f[nb], 0, 0, 0);
+            }
+            // register v of f[nb]: channel nb * 32 + (v & 3) + 8 (v >> 2) + 4 h of halo pixel p
+            const int gy = y0 - 1 + py, gx = x0 - 1 + pxx;
+            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.Wc;
+            if (p < NPA) {
+                const int sw = swz(p, NP);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = nb * 32 + 8 * j + 4 * h;
+                        const float4 bias = *reinterpret_cast<const float4*>(b1s + co);
+                        uintx2 o = uintx2{0u, 0u};
+                        if (inside)
+                            o = uintx2{pack2(fmaxf(f[nb][4 * j] + bias.x, 0.0f), fmaxf(f[nb][4 * j + 1] + bias.y, 0.0f)),
+                                       pack2(fmaxf(f[nb][4 * j + 2] + bias.z, 0.0f), fmaxf(f[nb][4 * j + 3] + bias.w, 0.0f))};
+                        *reinterpret_cast<uintx2*>(lds + A_OFF + p * ROWB + (((co >> 3) ^ sw) << 4) + (co & 7) * 2) = o;
+                    }
+            }
+        }
+        __syncthreads();
+    } else {
+        copy_rows(x_rsrc, lds + A_OFF, a_src, a_soff(0), wave, NA_INSTR);
+        issue_b(0, 0);
+    }
     for (int c = 0; c < nChunks; ++c) {
         const int a_buf = A_OFF + (c & 1) * A_BYTES;
 #pragma unroll
@@ -384,23 +468,23 @@ constexpr int lds_bytes(bool one_chunk) {
 
 std::mutex g_opt_in_mutex;
 
-template <int KS, int CK, int BN, int POOL, bool OUT_F32>
+template <int KS, int CK, int BN, int POOL, bool OUT_F32, bool FIRST = false>
 int launch_variant_t(const TileArgs& a, int64_t wgs, hipStream_t s) {
     static bool opted[64] = {};
     int dev = 0;
     OCR_HIP_CHECK(hipGetDevice(&dev));
-    constexpr int bytes_max = lds_bytes<KS, CK, BN>(false);
+    constexpr int bytes_max = lds_bytes<KS, CK, BN>(false) + (FIRST ? kPatchBytes : 0);
     const int n_chunks = (KS == 3 ? a.cin : a.row_bytes / 2) / CK;
-    const int bytes = lds_bytes<KS, CK, BN>(n_chunks == 1);
+    const int bytes = lds_bytes<KS, CK, BN>(n_chunks == 1) + (FIRST ? kPatchBytes : 0);
     {
         std::lock_guard<std::mutex> lock(g_opt_in_mutex);
         if (!opted[dev & 63]) {
-            OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16t_kernel<KS, CK, BN, POOL, OUT_F32>),
+            OCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16t_kernel<KS, CK, BN, POOL, OUT_F32, FIRST>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes_max));
             opted[dev & 63] = true;
         }
     }
-    hipLaunchKernelGGL((conv_bf16t_kernel<KS, CK, BN, POOL, OUT_F32>), dim3((unsigned)wgs), dim3(512), bytes, s, a);
+    hipLaunchKernelGGL((conv_bf16t_kernel<KS, CK, BN, POOL, OUT_F32, FIRST>), dim3((unsigned)wgs), dim3(512), bytes, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }
@@ -489,6 +573,48 @@ int launch_conv3_bf16t(const ConvLayer& L, const uint16_t* x, uint16_t* y, int B
 #undef OCR_T_CASE
     set_error("conv3_bf16t: no kernel variant for cin=%d cout=%d pool=%d", L.cin, L.cout, pool);
     return OCRHIP_EINVAL;
+}
+
+// The 3 -> 64 first layer as matrix-instruction row operands: [nb][kk][lane = h * 32 + r][8] bfloat16, element e = weight
+// of channel nb * 32 + r at k = kk * 16 + h * 8 + e, k = (ky * 3 + kx) * 3 + c, zero for k >= 27.
+int prepare_first_pair_bf16t(ConvLayer& first, const float* w_oihw) {
+    OCR_REQUIRE(first.cin == 3 && first.cout == 64 && first.ks == 3, "first_pair: expected the 3 -> 64 3x3 layer");
+    std::vector<uint16_t> t(2 * 2 * 64 * 8, 0);
+    for (int nb = 0; nb < 2; ++nb)
+        for (int kk = 0; kk < 2; ++kk)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int k = kk * 16 + (l >> 5) * 8 + e, o = nb * 32 + (l & 31);
+                    if (k >= 27) continue;
+                    const __bf16 v = (__bf16)w_oihw[((size_t)o * 3 + k % 3) * 9 + k / 3];
+                    t[(((nb * 2 + kk) * 64) + l) * 8 + e] = __builtin_bit_cast(unsigned short, v);
+                }
+    OCR_TRY(first.w_bf16t.reserve(t.size() * sizeof(uint16_t)));
+    OCR_HIP_CHECK(hipMemcpy(first.w_bf16t.ptr, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return OCRHIP_OK;
+}
+
+// The detector's first two layers in one launch: page (B, H, W, 3) uint8 or normalised float32 -> first (3 -> 64, ReLU;
+// its float32 weights [k][64] and bias) -> L (64 -> 64, ReLU, 2x2 max-pool) -> y (B, H/2, W/2, 64) bfloat16.
+int launch_conv3_first_pair_bf16t(const ConvLayer& first, const ConvLayer& L, const void* page, bool page_u8, uint16_t* y, int B, int H,
+                                  int W, hipStream_t s) {
+    OCR_REQUIRE(first.direct && first.cin == 3 && first.cout == 64 && first.w_bf16t.ptr, "conv3_first_pair: the first layer must be the prepared 3 -> 64 layer");
+    OCR_REQUIRE(L.ks == 3 && L.cin == 64 && L.cout == 64 && L.w_bf16t.ptr, "conv3_first_pair: the second layer must be a 64 -> 64 bfloat16 tile layer");
+    OCR_REQUIRE(page && y && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv3_first_pair: bad arguments");
+    OCR_REQUIRE((int64_t)H * W * 64 * 2 < (1ll << 31), "conv3_first_pair: an image exceeds 2 GB");
+    TileArgs a{};
+    a.x = reinterpret_cast<const uint16_t*>(page); a.w = L.w_bf16t.as<uint16_t>(); a.bias = L.bias.as<float>(); a.y = y;
+    a.B = B; a.nin = 1; a.H = H; a.Wc = W; a.gap = 0; a.cin = 64; a.cout = 64; a.relu = 1;
+    a.page = page; a.w1 = first.w_bf16t.ptr; a.b1 = first.bias.as<float>(); a.page_u8 = page_u8 ? 1 : 0;
+    a.tiles_x = (W + 31) / 32;
+    a.tiles_per_image = a.tiles_x * ((H + 7) / 8);
+    a.n_tiles_n = 1;
+    const int64_t wgs = (int64_t)a.tiles_per_image * B;
+    OCR_REQUIRE(wgs < (1ll << 31), "conv3_first_pair: too many workgroups");
+    const double px = (double)B * H * W;
+    ProfScope prof("conv_bf16t<first pair,n64,pool1>", 2.0 * 9 * 64 * 64 * px + 2.0 * 27 * 64 * px * (340.0 / 256.0),
+                   px * (page_u8 ? 3.0 : 12.0) + 2.0 * px * 64 / 4.0, s);
+    return launch_variant_t<3, 64, 64, 1, false, true>(a, wgs, s);
 }
 
 // Flat GEMM y (M, cout) = x rows . W^T + bias.  ks 1: row m = the cin values at x + m*cin.  ks 2: x is (n, fh, fw, cin),
