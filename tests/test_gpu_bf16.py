@@ -49,6 +49,17 @@ def test_detector_taps_and_maps(ctx, shape):
     finally:
         ctx.set_option('bf16_tensors', 1)
     assert rel(got, old) <= 1e-2 and np.abs(got - old).max() > 0
+    # the first two layers as two launches (float32 first layer writing a bfloat16 tensor) instead of one: both forms
+    # against the oracle, and close to each other at the first tap
+    ctx.set_option('bf16_fuse_first', 0)
+    try:
+        two = ctx.east_forward(torch.from_numpy(img).cuda(), compute_dtype=BF16).cpu().numpy()
+        pool1_two = ctx.east_activation('pool1')
+    finally:
+        ctx.set_option('bf16_fuse_first', 1)
+    assert rel(pool1_two, taps[0].numpy()) <= 1e-2 and rel(two, ref.numpy()) <= 1e-2
+    ctx.east_forward(torch.from_numpy(img).cuda(), compute_dtype=BF16)
+    assert rel(ctx.east_activation('pool1'), pool1_two) <= 1e-2
 
 
 @pytest.mark.parametrize('n,Wpad,V', [(4, 160, 97), (33, 192, 97), (2, 64, 97), (1, 48, 97), (2, 1040, 97), (3, 128, 6719)])

@@ -29,9 +29,11 @@ def stage_name(kernel):
         kind = {'0': '', '2': '_mul', '3': '_h', '4': '_h'}[m.group(2)]
         return 'conv_wino4%s_f32<n%s,pool%s,tile%sx32>' % (kind, '128' if m.group(2) == '4' else '64', m.group(1),
                                                            '8' if m.group(2) in '34' else '16')
-    m = re.search(r'conv_bf16t_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)>', kernel)
+    m = re.search(r'conv_bf16t_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>', kernel)
     if m:
-        ks, ck, bn, pool, f32 = m.groups()
+        ks, ck, bn, pool, f32, first = m.groups()
+        if first == 'true':
+            return 'conv_bf16t<first pair,n%s,pool%s>' % (bn, pool)
         if ks == '3':
             return 'conv_bf16t<ks3,n%s,k%s,pool%s>' % (bn, ck, pool)
         return 'gemm_bf16t<n%s,k%s,%s>' % (bn, ck, 'f32' if f32 == 'true' else 'bf16')

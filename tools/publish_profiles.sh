@@ -18,4 +18,8 @@ if [ -d $P/trace16 ]; then
   tail -1 $P/bench_bf16.json.log > profiles/$R/bf16_bench.json.log
   python tools/pmc_mfma.py $P/mfma16 > profiles/$R/bf16_pmc_mfma_util.csv
 fi
+if [ -d $P/tracedef ]; then
+  cp $P/tracedef/bench_kernel_stats.csv profiles/$R/refdef_bench_kernel_stats.csv
+  tail -1 $P/bench_refdef.json.log > profiles/$R/refdef_bench.json.log
+fi
 python tools/profile_report.py profiles/$R > profiles/$R/kernel_report.md
