@@ -113,6 +113,9 @@ int ocrhip_destroy(ocrhip_handle h);
  *   "flat_gemm": 1 (default) runs the Dense layers, the LSTM input projections and the 2x2 convolutions as a flat
  *   GEMM with 256 x 128 tiles; 0 runs them on the implicit-GEMM convolution kernel (256 x 64 / spatial tiles).  Same
  *   arithmetic (a float32 fma chain over k in both).
+ *   "fuse_mean_rows": 1 (default) | 0: the float32 recogniser takes the mean over the 3 feature rows in the epilogue of the
+ *   extractor's last (2x2) convolution instead of writing the rows and averaging them in a kernel of its own; the same
+ *   sums in the same order.
  *   "fuse_ctc": 1 (default): when ocrhip_crnn_forward* is asked for tokens but not for logits, the class layer
  *   Dense(vocab) reduces every row to one (maximum, class) pair per block of 128 classes in its epilogue and the CTC
  *   kernel finishes the argmax over those pairs: the (rows, vocab) logits are never written or read.  0: logits go

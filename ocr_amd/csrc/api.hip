@@ -53,6 +53,7 @@ static thread_local int g_wino4_side_by_side = 1;
 int wino4_side_by_side_enabled() { return g_wino4_side_by_side; }
 void set_wino4_side_by_side(int on) { g_wino4_side_by_side = on; }
 static thread_local int g_fuse_ctc = 1;
+static thread_local int g_fuse_mean_rows = 1;
 static thread_local int g_wino4_wave_tiles = 2;
 int wino4_wave_tiles() { return g_wino4_wave_tiles; }
 void set_wino4_wave_tiles(int on) { g_wino4_wave_tiles = on; }
@@ -277,6 +278,7 @@ using namespace ocrhip;
         ocrhip::set_lstm_debug_drop((h)->lstm_debug_drop);          \
         ocrhip::set_flat_gemm((h)->flat_gemm);                      \
         ocrhip::g_fuse_ctc = (h)->fuse_ctc;                         \
+        ocrhip::g_fuse_mean_rows = (h)->fuse_mean_rows;             \
         ocrhip::set_current_workspace(&(h)->wino_ws);               \
         ocrhip::set_wino4_split((h)->wino4_split);                  \
         ocrhip::set_wino4_wave_tiles((h)->wino4_wave_tiles);        \
@@ -767,9 +769,14 @@ static int crnn_features_resnet(CrnnNet& net, const float* x, int n, int Wpad, f
     OCR_REQUIRE(H == 8, "crnn: internal size error (H=%d)", H);
     OCR_TRY(launch_pad_maxpool(cur, other, n, H, W, 512, 1, 1, 1, 1, 1, s));
     OCR_TRY(launch_conv_mfma(L[li++], other, cur, n * 4, 2, W + 2, 0, true, nullptr, 0, s));
-    OCR_TRY(launch_conv_mfma(L[li++], cur, other, n, 4, W + 1, 0, true, nullptr, 0, s));                  // (n,3,W,512)
-    OCR_REQUIRE(li == 32 && W == net.seq_len(Wpad), "crnn: internal layer count error");
-    OCR_TRY(launch_mean_rows(other, feats, n, 3, W, 512, s));
+    OCR_REQUIRE(li == 31 && W == net.seq_len(Wpad), "crnn: internal layer count error");
+    if (g_fuse_mean_rows && flat_gemm() && !compute_bf16() && L[li].w_gemm.ptr) {
+        // the last convolution and the mean over its 3 output rows in one kernel: (n,3,W,512) never reaches memory
+        OCR_TRY(launch_gemm_f32_mean_rows(L[li], cur, feats, n, 4, W + 1, true, s));
+    } else {
+        OCR_TRY(launch_conv_mfma(L[li], cur, other, n, 4, W + 1, 0, true, nullptr, 0, s));                // (n,3,W,512)
+        OCR_TRY(launch_mean_rows(other, feats, n, 3, W, 512, s));
+    }
     return OCRHIP_OK;
 }
 
@@ -790,8 +797,13 @@ static int crnn_features(CrnnNet& net, const float* x, int n, int Wpad, float* f
     OCR_TRY(launch_conv_mfma(net.conv[3], A, Bf, n, 16, Wpad / 4, 2, true, nullptr, 0, s));         // (n,8,W/4,128)
     OCR_TRY(launch_conv_mfma(net.conv[4], Bf, A, n, 8, Wpad / 4, 0, true, nullptr, 0, s));          // (n,8,W/4,256)
     OCR_TRY(launch_conv_mfma(net.conv[5], A, Bf, n, 8, Wpad / 4, 2, true, nullptr, 0, s));          // (n,4,W/4,256)
-    OCR_TRY(launch_conv_mfma(net.conv[6], Bf, A, n, 4, Wpad / 4, 0, true, nullptr, 0, s));          // (n,3,T,256)
-    OCR_TRY(launch_mean_rows(A, feats, n, 3, T, net.feat_c, s));
+    if (g_fuse_mean_rows && flat_gemm() && !compute_bf16() && net.conv[6].w_gemm.ptr) {
+        // the 2x2 convolution and the mean over its 3 output rows in one kernel: (n,3,T,256) never reaches memory
+        OCR_TRY(launch_gemm_f32_mean_rows(net.conv[6], Bf, feats, n, 4, Wpad / 4, true, s));
+    } else {
+        OCR_TRY(launch_conv_mfma(net.conv[6], Bf, A, n, 4, Wpad / 4, 0, true, nullptr, 0, s));      // (n,3,T,256)
+        OCR_TRY(launch_mean_rows(A, feats, n, 3, T, net.feat_c, s));
+    }
     return OCRHIP_OK;
 }
 
@@ -1209,6 +1221,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "wino4_side_by_side") == 0) {
         OCR_REQUIRE(value == 0 || value == 1, "set_option: wino4_side_by_side is 0 or 1");
         h->wino4_side_by_side = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "fuse_mean_rows") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: fuse_mean_rows is 0 or 1");
+        h->fuse_mean_rows = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "fuse_ctc") == 0) {

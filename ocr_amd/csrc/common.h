@@ -191,6 +191,7 @@ struct ocrhip_ctx {
     int wino4_side_by_side = 1;    // fused F(4x4,3x3) layers: a batch of images whose width leaves the 32-column tiles partly empty is tiled as one wide image, a zero column apart (1) or image by image (0)
     int wino4_split = 0;           // F(4x4,3x3) layers with >= 512 input channels: fused like the others (0), or transform once into `wino_ws` and multiply from it (1)
     ocrhip::DevBuf wino_ws;        // transformed tiles of the layer in flight
+    int fuse_mean_rows = 1;        // float32 recogniser: the mean over the feature rows in the epilogue of the extractor's last convolution (1) or as a kernel of its own (0)
     int fuse_ctc = 1;              // tokens without a logits request: class layer reduced to per-block maxima in its epilogue (1) or logits written and re-read (0)
     int bf16_tensors = 1;          // compute_dtype = OCRHIP_BF16: bfloat16 activations in HBM, tile kernels, bfloat16 recurrence (1); or the float32-tensor kernels with operands rounded on their way into LDS and a float32 recurrence (0)
     int flat_gemm = 1;             // 1x1 / 2x2 layers on the 256 x 128 flat GEMM (1) or on the implicit-GEMM convolution kernel (0)
@@ -258,6 +259,7 @@ void set_conv3x3_winograd(int on);
 // handle's "flat_gemm" option is on (the default) and the layer has neither pooling, upsampling nor a residual.
 int prepare_gemm_f32(ConvLayer& L, const float* w_oihw, const float* bias, int cout, int cin, int ks);
 int launch_gemm_f32(const ConvLayer& L, const float* x, float* y, int B, int H, int W, bool relu, hipStream_t s);
+int launch_gemm_f32_mean_rows(const ConvLayer& L, const float* x, float* y, int B, int H, int W, bool relu, hipStream_t s);
 // Dense(vocab) in front of greedy CTC: per row and block of 128 columns the largest value and its column, no logits
 int gemm_f32_column_blocks(const ConvLayer& L);
 int launch_gemm_f32_argmax(const ConvLayer& L, const float* x, int64_t M, float* pmax, int* pidx, hipStream_t s);

@@ -48,10 +48,17 @@ struct GemmArgs {
     int Hc, Wc, H, W, cin;
     int seg_len, seg_stride;
     int64_t x_elems;         // floats in x: where its buffer descriptors end
+    int pos_per_tile;        // MEAN: output positions (b, c) per M tile, each Hc consecutive rows of it
 };
 
-template <bool ARGMAX>
+// MODE 0: y = act(A W^T + bias).  MODE 1 (ARGMAX): see above.  MODE 2 (MEAN): the mean over the Hc output rows of every
+// (b, c) - GlobalAverage over the height that follows the extractor's last convolution (architectures/crnn_arch.py:
+// 223-226, 427-477) - leaves the kernel instead of the rows themselves: the M tile holds pos_per_tile positions with
+// their Hc rows next to each other, the epilogue passes 32 columns at a time through LDS, sums the rows of a position
+// in row order and divides by Hc (the arithmetic of the separate kernel), and writes y (B * Wc, N).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
+    constexpr bool ARGMAX = MODE == 1, MEAN = MODE == 2;
     __shared__ __attribute__((aligned(16))) float As[2][kAFloats];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBFloats];
 
@@ -65,8 +72,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
     const unsigned total = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const unsigned work = xcd * (total >> 3) + min(xcd, total & 7u) + slot;
     const int nb = (int)(work % (unsigned)a.n_blocks);
-    const int64_t m0 = (int64_t)(work / (unsigned)a.n_blocks) * kBM;
+    const int64_t tile = (int64_t)(work / (unsigned)a.n_blocks);
+    const int64_t m0 = tile * kBM;
     const int nK = a.K / kCK;
+    const int64_t pos0 = tile * a.pos_per_tile, n_pos = a.M / a.Hc;          // MEAN
 
     // the 4 rows this thread stages (row = tid / 4 + 64 i, 16-byte column tid % 4).  Loads and stores go through buffer
     // descriptors that start at the tile's first row (so that 32-bit offsets do for any size of x and y): a per-lane
@@ -78,15 +87,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
         const unsigned r = br % (unsigned)a.Hc, b = br / (unsigned)a.Hc;
         return (((int64_t)b * a.H + r) * a.W + c) * a.cin;
     };
-    const int64_t x_first = row_offset(m0);
+    auto mean_row_offset = [&](int ml) {                       // MEAN: tile row ml = position pos0 + ml / Hc, output row ml % Hc
+        const unsigned pos = (unsigned)(pos0 + ml / a.Hc), r = (unsigned)(ml % a.Hc);
+        const unsigned c = pos % (unsigned)a.Wc, b = pos / (unsigned)a.Wc;
+        return (((int64_t)b * a.H + r) * a.W + c) * a.cin;
+    };
+    const int64_t x_first = MEAN ? mean_row_offset(0) : row_offset(m0);
     const int64_t x_left = (a.x_elems - x_first) * 4;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.x + x_first), 0, (int)(x_left < 0x7fffffffll ? x_left : 0x7fffffffll), 0x00020000);
     int abase[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + (tid >> 2) + 64 * i;
-        abase[i] = (m < a.M) ? (int)((row_offset(m) - x_first + (tid & 3) * 4) * 4) : (int)0x80000000;
+        const int ml = (tid >> 2) + 64 * i;
+        const int64_t m = m0 + ml;
+        if (MEAN)
+            abase[i] = (ml < a.pos_per_tile * a.Hc && pos0 + ml / a.Hc < n_pos) ? (int)((mean_row_offset(ml) - x_first + (tid & 3) * 4) * 4) : (int)0x80000000;
+        else
+            abase[i] = (m < a.M) ? (int)((row_offset(m) - x_first + (tid & 3) * 4) * 4) : (int)0x80000000;
     }
     const float* wslab = a.w + (int64_t)nb * nK * kBFloats;
 
@@ -189,6 +207,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
             }
         }
     };
+    if (MEAN) {
+        constexpr int SS = 33;                                  // floats per staged row: the column reads of a position's rows hit 32 banks
+        float* S = &As[0][0];
+        static_assert(2 * kAFloats >= kBM * SS, "staging area");
+        __syncthreads();                                        // every wave is done with the operand images
+        const int col = tid & 31;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    float o = acc[r][nt][v] + biasv[nt];
+                    if (a.relu) o = fmaxf(o, 0.0f);
+                    S[(wave * 64 + r * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * SS + li] = o;
+                }
+            __syncthreads();
+            const int co = nb * kBN + nt * 32 + col;
+            for (int p = tid >> 5; p < a.pos_per_tile; p += 8) {
+                float sum = S[(p * a.Hc) * SS + col];
+                for (int r = 1; r < a.Hc; ++r) sum += S[(p * a.Hc + r) * SS + col];
+                if (pos0 + p < n_pos && co < a.N) a.y[(pos0 + p) * a.N + co] = sum / (float)a.Hc;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     if (ARGMAX) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -264,6 +309,7 @@ int launch_gemm_f32(const ConvLayer& L, const float* x, float* y, int B, int H, 
     a.seg_len = L.ks * L.cin;             // one kernel row: ks pixels of cin channels, contiguous in NHWC
     a.seg_stride = W * L.cin;
     a.x_elems = (int64_t)B * H * W * L.cin;
+    a.pos_per_tile = 0;
     OCR_REQUIRE((int64_t)B * H * W * L.cin < (1ll << 40) && a.M < (1ll << 31), "gemm_f32: input too large");
     OCR_REQUIRE((int64_t)(64 + 40) * a.N * 4 < (1ll << 31), "gemm_f32: N=%d too wide", a.N);          // a wave's store offsets are 32-bit
     const int64_t wgs = (a.M + kBM - 1) / kBM * a.n_blocks;
@@ -272,7 +318,35 @@ int launch_gemm_f32(const ConvLayer& L, const float* x, float* y, int B, int H, 
     std::snprintf(pname, sizeof(pname), "gemm_f32<ks%d,tile256x128>", L.ks);
     ProfScope prof(pname, 2.0 * (double)a.M * a.N * a.K,
                    4.0 * ((double)B * H * W * L.cin + (double)a.M * a.N + (double)a.N * a.K), s);
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm_f32_kernel<0>, dim3((unsigned)wgs), dim3(256), 0, s, a);
+    OCR_HIP_CHECK(hipGetLastError());
+    return OCRHIP_OK;
+}
+
+// x: (B, H, W, cin) NHWC through the 2x2 (or 1x1) layer L, then the mean over the output rows: y (B, W - ks + 1, cout).
+int launch_gemm_f32_mean_rows(const ConvLayer& L, const float* x, float* y, int B, int H, int W, bool relu, hipStream_t s) {
+    OCR_REQUIRE(L.w_gemm.ptr && (L.ks == 1 || L.ks == 2), "gemm_f32_mean_rows: layer not prepared");
+    OCR_REQUIRE(x && y && B > 0 && H >= L.ks && W >= L.ks, "gemm_f32_mean_rows: bad arguments B=%d H=%d W=%d", B, H, W);
+    GemmArgs a;
+    a.x = x; a.w = L.w_gemm.as<float>(); a.bias = L.bias_gemm.as<float>(); a.y = y; a.pmax = nullptr; a.pidx = nullptr;
+    a.N = L.cout; a.K = L.ks * L.ks * L.cin; a.relu = relu ? 1 : 0;
+    a.n_blocks = (L.cout + kBN - 1) / kBN;
+    a.H = H; a.W = W; a.cin = L.cin;
+    a.Hc = H - L.ks + 1; a.Wc = W - L.ks + 1;
+    OCR_REQUIRE(a.Hc >= 1 && a.Hc <= 16, "gemm_f32_mean_rows: %d output rows (1..16 supported)", a.Hc);
+    a.M = (int64_t)B * a.Hc * a.Wc;
+    a.pos_per_tile = kBM / a.Hc;
+    a.seg_len = L.ks * L.cin;
+    a.seg_stride = W * L.cin;
+    a.x_elems = (int64_t)B * H * W * L.cin;
+    OCR_REQUIRE((int64_t)B * H * W * L.cin < (1ll << 40) && a.M < (1ll << 31), "gemm_f32_mean_rows: input too large");
+    const int64_t n_pos = (int64_t)B * a.Wc;
+    const int64_t wgs = (n_pos + a.pos_per_tile - 1) / a.pos_per_tile * a.n_blocks;
+    OCR_REQUIRE(wgs < (1ll << 31), "gemm_f32_mean_rows: too many workgroups");
+    char pname[64];
+    std::snprintf(pname, sizeof(pname), "gemm_f32<ks%d,mean rows,tile256x128>", L.ks);
+    ProfScope prof(pname, 2.0 * (double)a.M * a.N * a.K, 4.0 * ((double)B * H * W * L.cin + (double)n_pos * a.N + (double)a.N * a.K), s);
+    hipLaunchKernelGGL(gemm_f32_kernel<2>, dim3((unsigned)wgs), dim3(256), 0, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }
@@ -288,12 +362,12 @@ int launch_gemm_f32_argmax(const ConvLayer& L, const float* x, int64_t M, float*
     a.N = L.cout; a.K = L.cin; a.relu = 0;
     a.n_blocks = gemm_f32_column_blocks(L);
     a.H = 1; a.W = (int)M; a.cin = L.cin; a.Hc = 1; a.Wc = (int)M; a.M = M;
-    a.seg_len = L.cin; a.seg_stride = (int)M * L.cin; a.x_elems = M * L.cin;
+    a.seg_len = L.cin; a.seg_stride = (int)M * L.cin; a.x_elems = M * L.cin; a.pos_per_tile = 0;
     const int64_t wgs = (a.M + kBM - 1) / kBM * a.n_blocks;
     OCR_REQUIRE(wgs < (1ll << 31), "gemm_f32_argmax: too many workgroups");
     ProfScope prof("gemm_f32_argmax<tile256x128>", 2.0 * (double)a.M * a.N * a.K,
                    4.0 * ((double)M * L.cin + 2.0 * (double)a.M * a.n_blocks + (double)a.N * a.K), s);
-    hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm_f32_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, a);
     OCR_HIP_CHECK(hipGetLastError());
     return OCRHIP_OK;
 }

@@ -452,6 +452,36 @@ def test_flat_gemm_matches_the_convolution_kernel(ctx):
         ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=97, seed=2))
 
 
+def test_mean_over_feature_rows_in_the_gemm_epilogue_is_bit_identical(ctx):
+    """`fuse_mean_rows = 1` (default): the extractor's last 2x2 convolution sums its 3 output rows in its epilogue, in row
+    order, and divides by 3 - the arithmetic of the separate kernel behind `fuse_mean_rows = 0`, on the same convolution
+    sums: identical features and logits (VGG and ResNet extractors, uniform and ragged batches, a batch whose positions
+    do not fill the last 85-position tile)."""
+    rng = np.random.default_rng(21)
+    widths = np.array([64] * 3 + [96] * 7 + [128] * 5 + [320], dtype=np.int32)
+    packed = torch.from_numpy(rng.uniform(-1, 1, int(64 * widths.sum())).astype(np.float32)).cuda()
+    x = torch.from_numpy(rng.uniform(-1, 1, (7, 64, 192, 1)).astype(np.float32)).cuda()
+    try:
+        for backbone in ('vgg', 'resnet'):
+            ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=97, seed=13, backbone=backbone))
+            a = ctx.crnn_forward_packed(packed, widths, want_logits=True)['logits'].cpu().numpy()
+            au = ctx.crnn_forward(x, want_logits=True)['logits'].cpu().numpy()
+            fa = ctx.crnn_activation('features')
+            ctx.set_option('fuse_mean_rows', 0)
+            try:
+                b = ctx.crnn_forward_packed(packed, widths, want_logits=True)['logits'].cpu().numpy()
+                bu = ctx.crnn_forward(x, want_logits=True)['logits'].cpu().numpy()
+                fb = ctx.crnn_activation('features')
+            finally:
+                ctx.set_option('fuse_mean_rows', 1)
+            assert np.isfinite(a).all() and np.abs(a).max() > 0
+            np.testing.assert_array_equal(fa, fb)
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(au, bu)
+    finally:
+        ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=97, seed=2))
+
+
 def test_bf16_variant_within_1e2_of_the_float32_oracle(ctx):
     """`compute_dtype = BF16`: bfloat16 operands, float32 accumulation.  Tolerance: relative error of the whole tensor
     ||got - ref|| / ||ref|| <= 1e-2 against the float32 oracle, and no single element further than 5e-2 of the tensor's
