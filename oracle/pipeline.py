@@ -59,3 +59,46 @@ def ocr_page(image_u8, east_params, crnn_params, tokenizer, maps_override=None, 
     _, boxes, _ = detect_page(image_u8, east_params, maps_override, **kw)
     index, texts, scores, logits = recognise_rows(image_u8, boxes, crnn_params, tokenizer, return_logits=True)
     return {'boxes': boxes, 'index': index, 'texts': texts, 'scores': scores, 'logits': logits}
+
+
+def ocr_pages_batched(images_u8, east_params, crnn_params, tokenizer, maps_override=None, **kw):
+    """The same arithmetic with the batching a CPU implementation would choose (not what the reference does): one EAST
+    forward over all pages, one recogniser forward per padded crop width over all rows of all pages.  Used only as the
+    "optimised CPU" figure beside the reference-faithful one in bench.py."""
+    n = len(images_u8)
+    run_network = kw.pop('run_network', True)
+    maps = None
+    if run_network:
+        x = np.stack([oimg.prepare_east_input(im) for im in images_u8])
+        maps = nets.east_forward(east_params, x).numpy()
+    per_page, rows = [], []
+    for b in range(n):
+        _, boxes, _ = detect_page(images_u8[b], east_params, None if maps_override is None else maps_override[b],
+                                  run_network=False, **kw)
+        per_page.append(boxes)
+        for i, box in enumerate(boxes):
+            _, crop = obox.crop_box(images_u8[b], box)
+            inp = oimg.prepare_crnn_input(crop)
+            if inp is None or any(s == 0 for s in inp.shape):
+                continue
+            rows.append((b, i, inp))
+    logits = [None] * len(rows)
+    by_width = {}
+    for k, (_, _, inp) in enumerate(rows):
+        by_width.setdefault(inp.shape[1], []).append(k)
+    for _, ks in sorted(by_width.items()):
+        out = nets.crnn_forward(crnn_params, np.stack([rows[k][2] for k in ks])).numpy()
+        for j, k in enumerate(ks):
+            logits[k] = out[j]
+    results = [{'boxes': per_page[b], 'index': [], 'texts': [], 'scores': []} for b in range(n)]
+    if rows:
+        lengths = np.array([len(o) for o in logits], dtype=np.int32)
+        padded = np.zeros((len(rows), int(lengths.max()), logits[0].shape[1]), dtype=np.float32)
+        for k, o in enumerate(logits):
+            padded[k, :len(o)] = o
+        texts, scores = tokenizer.ctc_decode(padded, lengths)
+        for k, (b, i, _) in enumerate(rows):
+            results[b]['index'].append(i)
+            results[b]['texts'].append(texts[k])
+            results[b]['scores'].append(scores[k])
+    return results

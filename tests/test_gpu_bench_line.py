@@ -32,6 +32,7 @@ def test_bench_prints_one_line_with_roofline_and_cpu_baseline():
     assert 0.0 < roof['frac'] <= 1.0 and 'traffic' in roof and roof['launches'] > 0
     base = line['cpu_baseline']
     assert base['kind'] == 'port' and base['unit'] == 'images/s' and base['value'] > 0 and base['cores'] >= 1 and base['sample']
+    assert base['batched']['value'] > 0 and base['batched']['unit'] == 'images/s' and base['batched']['sample']
     names = {e['kernel'] for e in line['roofline_hbm']}
     assert {'east_decode', 'lanms', 'crop_resize_pack'} <= names
     for e in line['roofline_hbm']:

@@ -222,3 +222,22 @@ def test_c_lanms_equals_numpy_lanms_on_decoded_pages(seed, method):
     assert len(boxes) > 1000
     ref = _same_as_numpy_lanms(boxes, scores, nms_threshold=0.2, merge_threshold=0.3, merge_method=method)
     assert 10 <= int(ref[2].sum()) <= 60 and ref[4] >= 2
+
+
+def test_batched_cpu_pipeline_gives_the_per_row_pipeline_strings():
+    """bench.py reports a second CPU figure: the oracle pipeline batched the way a CPU implementation would (one
+    recogniser forward per crop width).  Same arithmetic, so the same rows, strings and scores as the reference-faithful
+    one-forward-per-row path."""
+    from ocr_amd import synth
+    from ocr_amd.utils.text import ENGLISH_G2_CHARACTERS
+    from oracle import ctc as octc, nets, pipeline as opipe
+    ep, cp = nets.init_east_params(seed=3), nets.init_crnn_params(vocab_size=97, seed=4)
+    tok = octc.CharTokenizer(ENGLISH_G2_CHARACTERS)
+    images, maps, _ = synth.make_pages(5, 2, 128, 256, 8)
+    per_row = [opipe.ocr_page(images[b], ep, cp, tok, maps_override=maps[b], run_network=False) for b in range(2)]
+    batched = opipe.ocr_pages_batched(images, ep, cp, tok, maps_override=maps, run_network=False)
+    assert sum(len(p['texts']) for p in per_row) >= 6
+    for a, b in zip(per_row, batched):
+        assert list(a['index']) == list(b['index']) and list(a['texts']) == list(b['texts'])
+        np.testing.assert_array_equal(a['boxes'], b['boxes'])
+        np.testing.assert_allclose(a['scores'], b['scores'], rtol=1e-4, atol=1e-5)
