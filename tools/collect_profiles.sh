@@ -26,6 +26,9 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 echo "bf16 trace done"
 timeout -s KILL 280 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma16 -o m -- python3 bench.py --dtype bf16 --no-cpu-baseline --steps 1 --warmup 1 > $OUT/mfma16.log 2>&1
 echo "bf16 mfma done"
+timeout -s KILL 280 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch16 -o f -- python3 bench.py --dtype bf16 --no-cpu-baseline --steps 1 --warmup 1 > $OUT/fetch16.log 2>&1
+timeout -s KILL 280 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write16 -o w -- python3 bench.py --dtype bf16 --no-cpu-baseline --steps 1 --warmup 1 > $OUT/write16.log 2>&1
+echo "bf16 traffic done"
 # the reference's default arguments (grouped lines, beam search with 10 beams): kernel trace of a short run
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tracedef -o bench -- python3 bench.py --reference-defaults --steps 10 --warmup 2 > $OUT/bench_refdef.json.log 2> $OUT/tracedef.err
 echo "reference-defaults trace done"

@@ -63,19 +63,22 @@ def totals(d):
     return acc
 
 
-def main(fetch_dir, write_dir):
-    f, w = totals(fetch_dir), totals(write_dir)
+def main(pairs):
+    """pairs: (fetch_dir, write_dir) per measured command (float32 run, bfloat16 run): their kernels have different names."""
     out = {}
-    for k in sorted(set(f) & set(w)):
-        if f[k][0] != w[k][0]:
-            continue                      # the two passes must have seen the same launches
-        n = f[k][0]
-        fetch, write = f[k][1] / n * 1024.0, w[k][1] / n * 1024.0
-        out[k] = {'launches': n, 'fetch_size_bytes_per_launch': fetch, 'write_size_bytes_per_launch': write,
-                  'traffic_bytes_per_launch': 2.0 * fetch + write}
-    json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1',
+    for fetch_dir, write_dir in pairs:
+        f, w = totals(fetch_dir), totals(write_dir)
+        for k in sorted(set(f) & set(w)):
+            if f[k][0] != w[k][0] or k in out:
+                continue                  # the two passes must have seen the same launches; the first command that ran a kernel names it
+            n = f[k][0]
+            fetch, write = f[k][1] / n * 1024.0, w[k][1] / n * 1024.0
+            out[k] = {'launches': n, 'fetch_size_bytes_per_launch': fetch, 'write_size_bytes_per_launch': write,
+                      'traffic_bytes_per_launch': 2.0 * fetch + write}
+    json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py [--dtype bf16] --no-cpu-baseline --steps 1 --warmup 1',
                'correction': 'traffic = 2 x FETCH_SIZE + WRITE_SIZE', 'kernels': out}, sys.stdout, indent=1)
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    a = sys.argv[1:]
+    main([(a[i], a[i + 1]) for i in range(0, len(a) - 1, 2)])

@@ -7,7 +7,13 @@ P=gpurun_out/prof
 mkdir -p profiles/$R
 cp $P/trace/bench_kernel_stats.csv profiles/$R/bench_kernel_stats.csv
 tail -1 $P/bench_default.json.log > profiles/$R/bench_default.json.log
-python tools/pmc_traffic.py $P/fetch $P/write > profiles/pmc_traffic.json
+if [ -d $P/fetch16 ]; then
+  python tools/pmc_traffic.py $P/fetch $P/write $P/fetch16 $P/write16 > profiles/pmc_traffic.json
+  python tools/pmc_summary.py $P/fetch16 > profiles/$R/bf16_pmc_fetch_size.csv
+  python tools/pmc_summary.py $P/write16 > profiles/$R/bf16_pmc_write_size.csv
+else
+  python tools/pmc_traffic.py $P/fetch $P/write > profiles/pmc_traffic.json
+fi
 python tools/pmc_summary.py $P/fetch > profiles/$R/pmc_fetch_size.csv
 python tools/pmc_summary.py $P/write > profiles/$R/pmc_write_size.csv
 python tools/pmc_mfma.py $P/mfma > profiles/$R/pmc_mfma_util.csv
