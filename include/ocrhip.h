@@ -83,6 +83,10 @@ int ocrhip_destroy(ocrhip_handle h);
  *   "bf16_fuse_first": 1 (default) | 0: the bfloat16-tensor detector computes its first layer (3 -> 64) inside the second
  *   layer's kernel, per tile, from the page pixels (bfloat16 operands like every other layer of that path), so the
  *   full-resolution 64-channel tensor is never written; 0 runs the float32 first-layer kernel and stores its result.
+ *   "crnn_side_streams": 1 (default) | 0: ocrhip_crnn_forward_packed runs the feature extractor of a batch with many
+ *   small groups of equal-width crops (4 or more groups of fewer than 256 crops on average: grouped lines of text) on
+ *   the caller's stream and three side streams of the handle, joined before the BiLSTM; same results, the launches of
+ *   different groups overlap.  0: everything on the caller's stream.
  *   "lstm16_units": 64 (default) | 32: hidden units a workgroup of the bfloat16 recurrence (compute_dtype OCRHIP_BF16)
  *   keeps of W_hh in LDS.  Every workgroup reads all of h_{t-1} of its sequences, so 64 units (4 workgroups per sequence
  *   group instead of 8) halve the hand-over reads; same results.

@@ -332,6 +332,12 @@ int ocrhip_destroy(ocrhip_handle h) {
     }
     free_layer(h->crnn.pred);
     for (auto& b : h->crnn.act) b.release();
+    for (int i = 0; i < CrnnNet::kAux; ++i) {
+        for (auto& b : h->crnn.act_aux[i]) b.release();
+        if (h->crnn.aux_stream[i]) (void)hipStreamDestroy(h->crnn.aux_stream[i]);
+        if (h->crnn.aux_join[i]) (void)hipEventDestroy(h->crnn.aux_join[i]);
+    }
+    if (h->crnn.aux_fork) (void)hipEventDestroy(h->crnn.aux_fork);
     for (DevBuf* b : {&h->crnn.feats, &h->crnn.xw, &h->crnn.hbuf, &h->crnn.cbuf, &h->crnn.seq, &h->crnn.lin, &h->crnn.logits, &h->crnn.seq16, &h->crnn.meta, &h->crnn.lstm_counters, &h->crnn.pmax, &h->crnn.pidx})
         b->release();
     h->crnn.ring.release();
@@ -782,15 +788,16 @@ static int crnn_features_resnet(CrnnNet& net, const float* x, int n, int Wpad, f
 
 // Feature extractor for a batch of equal-width crops: (n,64,Wpad,1) -> feats (n,T,feat_c).
 // VGG: T = Wpad/4 - 1, 256 features.
-static int crnn_features(CrnnNet& net, const float* x, int n, int Wpad, float* feats, hipStream_t s) {
+// `act`: the two activation buffers of the stream `s` (the net's own, or those of a side stream).
+static int crnn_features(CrnnNet& net, DevBuf* act, const float* x, int n, int Wpad, float* feats, hipStream_t s) {
     if (net.backbone) return crnn_features_resnet(net, x, n, Wpad, feats, s);
     const int Hin = 64;
     const int T = Wpad / 4 - 1;
     const size_t nW = (size_t)n * Wpad;
-    OCR_TRY(net.act[0].reserve(nW * 512 * sizeof(float)));      // (n,32,W/2,32) is the largest
-    OCR_TRY(net.act[1].reserve(nW * 256 * sizeof(float)));      // (n,16,W/4,64)
-    float* A = net.act[0].as<float>();
-    float* Bf = net.act[1].as<float>();
+    OCR_TRY(act[0].reserve(nW * 512 * sizeof(float)));          // (n,32,W/2,32) is the largest
+    OCR_TRY(act[1].reserve(nW * 256 * sizeof(float)));          // (n,16,W/4,64)
+    float* A = act[0].as<float>();
+    float* Bf = act[1].as<float>();
     OCR_TRY(launch_conv_first(net.conv[0], x, false, A, n, Hin, Wpad, 1, s));                       // (n,32,W/2,32)
     OCR_TRY(launch_conv_mfma(net.conv[1], A, Bf, n, 32, Wpad / 2, 1, true, nullptr, 0, s));         // (n,16,W/4,64)
     OCR_TRY(launch_conv_mfma(net.conv[2], Bf, A, n, 16, Wpad / 4, 0, true, nullptr, 0, s));         // (n,16,W/4,128)
@@ -917,13 +924,13 @@ static int crnn_report_timeout(CrnnNet& net, hipStream_t s) {
 // ---- the VGG recogniser on bfloat16 tensors (`compute_dtype = OCRHIP_BF16`, option bf16_tensors = 1)
 // Crops of one width are tiled side by side in every 3x3 layer (one zero column apart, two under 2x2 pooling): the
 // 32-column tiles are full whatever the crop width.
-static int crnn_features16(CrnnNet& net, const float* x, int n, int Wpad, uint16_t* feats16, hipStream_t s) {
+static int crnn_features16(CrnnNet& net, DevBuf* act, const float* x, int n, int Wpad, uint16_t* feats16, hipStream_t s) {
     const int T = Wpad / 4 - 1;
     const size_t nW = (size_t)n * Wpad;
-    OCR_TRY(net.act[0].reserve(nW * 512 * sizeof(float)));
-    OCR_TRY(net.act[1].reserve(nW * 256 * sizeof(float)));
-    uint16_t* A = net.act[0].as<uint16_t>();
-    uint16_t* Bf = net.act[1].as<uint16_t>();
+    OCR_TRY(act[0].reserve(nW * 512 * sizeof(float)));
+    OCR_TRY(act[1].reserve(nW * 256 * sizeof(float)));
+    uint16_t* A = act[0].as<uint16_t>();
+    uint16_t* Bf = act[1].as<uint16_t>();
     OCR_TRY(launch_conv_first(net.conv[0], x, false, A, n, 64, Wpad, 1, s, true));                      // (n,32,W/2,32)
     OCR_TRY(launch_conv3_bf16t(net.conv[1], A, Bf, 1, n, 32, Wpad / 2, 2, 1, true, s));                  // (n,16,W/4,64)
     OCR_TRY(launch_conv3_bf16t(net.conv[2], Bf, A, 1, n, 16, Wpad / 4, 1, 0, true, s));                  // (n,16,W/4,128)
@@ -1033,7 +1040,7 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
     net.taps.clear();
     if (crnn_use_bf16_tensors(h, compute_dtype)) {
         uint16_t* feats16 = net.feats.as<uint16_t>();
-        OCR_TRY(crnn_features16(net, reinterpret_cast<const float*>(d_crops), n, Wpad, feats16, s));
+        OCR_TRY(crnn_features16(net, net.act, reinterpret_cast<const float*>(d_crops), n, Wpad, feats16, s));
         record(net.taps, "features", feats16, n, T, Fc, 1, true);
         float* lg = d_logits;
         if (!lg) {
@@ -1044,7 +1051,7 @@ int ocrhip_crnn_forward(ocrhip_handle h, const void* d_crops, int n, int Wpad, i
         if (d_tokens) OCR_TRY(launch_ctc_greedy(lg, n, T, net.vocab, net.vocab, nullptr, nullptr, 0, d_tokens, d_scores, s));
         return OCRHIP_OK;
     }
-    OCR_TRY(crnn_features(net, reinterpret_cast<const float*>(d_crops), n, Wpad, feats, s));
+    OCR_TRY(crnn_features(net, net.act, reinterpret_cast<const float*>(d_crops), n, Wpad, feats, s));
     record(net.taps, "features", feats, n, T, Fc, 1);
     float* logits = d_logits;
     const bool fused = !logits && crnn_can_fuse_ctc(net);
@@ -1110,22 +1117,57 @@ int ocrhip_crnn_forward_packed(ocrhip_handle h, const void* d_packed, const int*
     const int64_t max_elems = net.backbone ? (1ll << 18) : (1ll << 20);      // n_group * Wpad per pass (2 GB per buffer at most)
     const float* x = reinterpret_cast<const float*>(d_packed);
     const bool tensors16 = crnn_use_bf16_tensors(h, compute_dtype);
-    int64_t off = 0;
+    // Groups of equal width.  Where they are many and small (the lines of grouped text: a few crops per width), a group's
+    // launches fill a fraction of the GPU, and groups go round-robin over the caller's stream and kAux side streams, each
+    // with activation buffers of its own (sized before the first launch: no buffer grows while a launch may still read it)
+    int n_groups = 0;
+    size_t max_nw = 0;
     for (int i = 0; i < n;) {
+        int j = i;
+        while (j < n && out_w[j] == out_w[i]) ++j;
+        max_nw = std::max(max_nw, (size_t)std::min<int64_t>((int64_t)(j - i) * out_w[i], std::max<int64_t>(max_elems, out_w[i])));
+        ++n_groups;
+        i = j;
+    }
+    const bool side = h->crnn_side_streams && !net.backbone && !h->wino4_split && n_groups >= 4 && n / n_groups < 256;
+    if (side) {
+        if (!net.aux_fork) OCR_HIP_CHECK(hipEventCreateWithFlags(&net.aux_fork, hipEventDisableTiming));
+        for (int a = 0; a < CrnnNet::kAux; ++a) {
+            if (!net.aux_stream[a]) OCR_HIP_CHECK(hipStreamCreateWithFlags(&net.aux_stream[a], hipStreamNonBlocking));
+            if (!net.aux_join[a]) OCR_HIP_CHECK(hipEventCreateWithFlags(&net.aux_join[a], hipEventDisableTiming));
+            OCR_TRY(net.act_aux[a][0].reserve(max_nw * 512 * sizeof(float)));
+            OCR_TRY(net.act_aux[a][1].reserve(max_nw * 256 * sizeof(float)));
+        }
+        OCR_TRY(net.act[0].reserve(max_nw * 512 * sizeof(float)));
+        OCR_TRY(net.act[1].reserve(max_nw * 256 * sizeof(float)));
+        OCR_HIP_CHECK(hipEventRecord(net.aux_fork, s));          // the crops and the uploads above are in place
+        for (int a = 0; a < CrnnNet::kAux; ++a) OCR_HIP_CHECK(hipStreamWaitEvent(net.aux_stream[a], net.aux_fork, 0));
+    }
+    int64_t off = 0;
+    int g = 0;
+    for (int i = 0; i < n; ++g) {
         const int w = out_w[i];
         int j = i;
         while (j < n && out_w[j] == w) ++j;
+        const int lane_id = side ? g % (CrnnNet::kAux + 1) : 0;          // 0: the caller's stream
+        hipStream_t gs = lane_id ? net.aux_stream[lane_id - 1] : s;
+        DevBuf* act = lane_id ? net.act_aux[lane_id - 1] : net.act;
         const int per_pass = (int)std::max<int64_t>(1, max_elems / w);
         for (int c0 = i; c0 < j; c0 += per_pass) {
             const int c1 = std::min(j, c0 + per_pass);
             if (tensors16)
-                OCR_TRY(crnn_features16(net, x + off, c1 - c0, w, net.feats.as<uint16_t>() + (size_t)meta[n + c0] * Fc, s));
+                OCR_TRY(crnn_features16(net, act, x + off, c1 - c0, w, net.feats.as<uint16_t>() + (size_t)meta[n + c0] * Fc, gs));
             else
-                OCR_TRY(crnn_features(net, x + off, c1 - c0, w, feats + (size_t)meta[n + c0] * Fc, s));
+                OCR_TRY(crnn_features(net, act, x + off, c1 - c0, w, feats + (size_t)meta[n + c0] * Fc, gs));
             off += (int64_t)(c1 - c0) * 64 * w;
         }
         i = j;
     }
+    if (side)
+        for (int a = 0; a < CrnnNet::kAux; ++a) {
+            OCR_HIP_CHECK(hipEventRecord(net.aux_join[a], net.aux_stream[a]));
+            OCR_HIP_CHECK(hipStreamWaitEvent(s, net.aux_join[a], 0));
+        }
     record(net.taps, "features", feats, 1, R, Fc, 1, tensors16);
     if (tensors16) {
         float* lg = d_logits;
@@ -1191,6 +1233,11 @@ int ocrhip_set_option(ocrhip_handle h, const char* name, int value) {
     if (std::strcmp(name, "bf16_fuse_first") == 0) {
         OCR_REQUIRE(value == 0 || value == 1, "set_option: bf16_fuse_first is 0 or 1");
         h->bf16_fuse_first = value;
+        return OCRHIP_OK;
+    }
+    if (std::strcmp(name, "crnn_side_streams") == 0) {
+        OCR_REQUIRE(value == 0 || value == 1, "set_option: crnn_side_streams is 0 or 1");
+        h->crnn_side_streams = value;
         return OCRHIP_OK;
     }
     if (std::strcmp(name, "lstm16_units") == 0) {

@@ -157,6 +157,12 @@ struct CrnnNet {
     ConvLayer linear[2];     // 512 -> 256
     ConvLayer pred;          // 256 -> vocab
     DevBuf act[3];
+    // many small groups of equal-width crops (lines of text): the feature extractor of a group runs on one of kAux side
+    // streams with activation buffers of its own, so that launches which fill a fraction of the GPU overlap
+    static constexpr int kAux = 3;
+    DevBuf act_aux[kAux][2];
+    hipStream_t aux_stream[kAux] = {nullptr, nullptr, nullptr};
+    hipEvent_t aux_fork = nullptr, aux_join[kAux] = {nullptr, nullptr, nullptr};
     DevBuf feats, xw, hbuf, cbuf, seq, lin, logits, meta, lstm_counters;
     DevBuf seq16;            // bfloat16-tensor path: output rows of a BiLSTM layer (R, 2H)
     DevBuf pmax, pidx;       // greedy decoding without logits: per row and block of 128 classes the maximum and its class
@@ -184,6 +190,7 @@ struct ocrhip_ctx {
     int lstm_debug_drop = 0;       // test hook: the persistent recurrence withholds one hand-over and times out quickly
     int lstm_persistent = 2;       // recurrence of a BiLSTM layer in one persistent launch: independent waves on blocks of 16 sequences where a workgroup has at least 8 blocks, workgroup-wide passes of 112 sequences otherwise (2), passes always (1), independent waves always (3); or one launch per step (0)
     int bf16_fuse_first = 1;       // bfloat16-tensor detector: the first two layers (3 -> 64, 64 -> 64 + pool) in one launch
+    int crnn_side_streams = 1;     // recogniser: feature extractor of small width groups on side streams (1) or all on the caller's stream (0)
     int lstm16_units = 64;         // bfloat16 recurrence: hidden units per workgroup (128 KB of W_hh in LDS, 4 workgroups share a sequence group) or 32
     int conv3x3_winograd = 2;      // 3x3 convolutions by Winograd F(2x2,3x3) (1) or as direct implicit GEMM (0)
     int first_layer_mfma = 1;      // the detector's 3 -> 64 first layer on the matrix cores (1) or on the vector ALU (0); identical results

@@ -117,6 +117,7 @@ class HipContext:
         sequences for large batches, workgroup-wide passes otherwise), 1 passes always, 3 independent waves always,
         0 one launch per time step.
         'lstm16_units': 64 (default) or 32 hidden units per workgroup of the bfloat16 recurrence.
+        'crnn_side_streams': 1 (default) many small width groups of a packed batch run on side streams, 0 on one stream.
         'fuse_mean_rows': 1 (default) the mean over the feature rows in the last convolution's epilogue, 0 a kernel of its own.
         'bf16_fuse_first': 1 (default) the bfloat16 detector's first two layers in one launch, 0 two launches.
         'wino4_split': 0 (default) every F(4x4,3x3) layer fused, 1 layers with >= 512 input channels as transform kernel +

@@ -482,6 +482,29 @@ def test_mean_over_feature_rows_in_the_gemm_epilogue_is_bit_identical(ctx):
         ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=97, seed=2))
 
 
+def test_width_groups_on_side_streams_give_identical_results(ctx):
+    """Many small groups of equal-width crops (lines of grouped text) run their feature extractors on the caller's stream
+    and three side streams with buffers of their own (`crnn_side_streams = 1`, default); everything on one stream
+    (`= 0`) must give the same bits, in both precisions, also when calls follow each other without a host wait."""
+    from ocr_amd._lib import BF16, F32
+    rng = np.random.default_rng(33)
+    widths = np.sort(rng.choice(np.arange(64, 1500, 64), 40)).astype(np.int32)          # ~20 distinct widths, 1-4 crops each
+    packed = torch.from_numpy(rng.uniform(-1, 1, int(64 * widths.sum())).astype(np.float32)).cuda()
+    ctx.crnn_load_weights(nets.init_crnn_params(vocab_size=97, seed=2))
+    for dt in (F32, BF16):
+        outs = [ctx.crnn_forward_packed(packed, widths, want_logits=True, compute_dtype=dt)['logits'] for _ in range(3)]
+        torch.cuda.synchronize()
+        ctx.check_errors()
+        ctx.set_option('crnn_side_streams', 0)
+        try:
+            ref = ctx.crnn_forward_packed(packed, widths, want_logits=True, compute_dtype=dt)['logits'].cpu().numpy()
+        finally:
+            ctx.set_option('crnn_side_streams', 1)
+        assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+        for o in outs:
+            np.testing.assert_array_equal(o.cpu().numpy(), ref)
+
+
 def test_bf16_variant_within_1e2_of_the_float32_oracle(ctx):
     """`compute_dtype = BF16`: bfloat16 operands, float32 accumulation.  Tolerance: relative error of the whole tensor
     ||got - ref|| / ||ref|| <= 1e-2 against the float32 oracle, and no single element further than 5e-2 of the tensor's
