@@ -112,6 +112,14 @@ def test_ragged_batch_and_the_per_step_fallback(ctx):
     finally:
         ctx.set_option('lstm_persistent', 2)
     assert rel(b, f32) <= 1e-2
+    # 32 hidden units per workgroup of the recurrence instead of 64: the same sums in the same order
+    ctx.set_option('lstm16_units', 32)
+    try:
+        u32 = ctx.crnn_forward_packed(packed, widths, want_logits=True, compute_dtype=BF16)['logits'].cpu().numpy()
+        ctx.check_errors()
+    finally:
+        ctx.set_option('lstm16_units', 64)
+    np.testing.assert_array_equal(u32, lg)
     # the widest crop alone
     k = len(widths) - 1
     alone = packed[64 * int(widths[:k].sum()):].contiguous()
