@@ -376,6 +376,8 @@ def main():
                                         'runs and is timed',
                        'parallelism': 'image-sharded x%d, one shared batch queue, boxes + strings gathered on the host of '
                                       'rank 0 inside the timed region' % world,
+                       'bracket_collectives': ('none (one process)' if dist is None else
+                                               {'nccl': 'rccl', 'gloo': 'gloo'}.get(dist.get_backend(), str(dist.get_backend()))),
                        'input': 'uint8 pages resident in HBM' if args.resident else
                                 'pinned host uint8, H2D timed (copy stream, one batch ahead of the compute stream)',
                        'batches_taken_by_rank0': len(local), 'batches_given_back_by_rank0': len(retried)},

@@ -84,10 +84,10 @@ def _init_from_env(backend, device):
     if not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        kwargs = {}
-        if backend == 'nccl' and device is not None:
-            kwargs['device_id'] = device
-        dist.init_process_group(backend, **kwargs)
+        if backend == 'nccl':
+            _init_rccl_or_gloo(dist, device)
+        else:
+            dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     # host-side collectives (python objects) never go through the GPUs
     host_group = dist.new_group(backend='gloo') if dist.get_backend() != 'gloo' else dist.group.WORLD
@@ -102,6 +102,32 @@ def _init_from_env(backend, device):
     _stores.append(store)                     # the server must outlive a caller that drops the Group
     dist.barrier(group=host_group)            # every client is connected before anybody goes on
     return Group(rank, world, dist, host_group, store)
+
+
+def _init_rccl_or_gloo(dist, device):
+    """RCCL for the job's two bracket collectives (a barrier, a MAX of one double).  The data path has no collective, so
+    a node whose RCCL cannot come up (two ranks given the same GPU, a fabric that is down) still runs: every rank then
+    sees the same failure while the communicator is being built, and the job's collectives go over gloo on the host
+    instead.  (A second rendezvous needs a second port: MASTER_PORT + 1.)"""
+    import datetime
+    import sys
+    kwargs = {'device_id': device} if device is not None else {}
+    try:
+        dist.init_process_group('nccl', timeout=datetime.timedelta(seconds=300), **kwargs)
+        t = torch.zeros(1, device=device if device is not None else 'cuda')
+        dist.all_reduce(t)                        # builds the communicator if the call above did not
+        torch.cuda.synchronize()
+        return
+    except Exception as e:                        # noqa: BLE001 - whatever the backend raises, the job can go on without it
+        sys.stderr.write('ocr_amd.dist: RCCL did not come up (%s: %s); the bracket collectives use gloo\n'
+                         % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else ''))
+    try:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:                             # noqa: BLE001
+        pass
+    os.environ['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500')) + 1)
+    dist.init_process_group('gloo')
 
 
 class QueueAborted(RuntimeError):
@@ -272,6 +298,7 @@ def max_over_ranks(value, dist, device=None):
     """MAX all-reduce of a host float (the elapsed time of the slowest rank)."""
     if dist is None:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else 'cpu')
+    on_host = device is None or dist.get_backend() == 'gloo'
+    t = torch.tensor([float(value)], dtype=torch.float64, device='cpu' if on_host else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
